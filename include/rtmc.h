@@ -1,0 +1,269 @@
+/*
+ * rtmc.h -- C ABI of librtmc.so, the MI355X photon-transport library.
+ *
+ * The reference (mohrezaeib/RayTracer) is pure Python and has no FFI of its
+ * own; the boundary this library replaces is the body of
+ * RayTrace.runSimulation (reference RayTrace.py:157-204): the per-photon
+ * `while active:` loop (RayTrace.py:178-195) and everything it calls.  A host
+ * program describes the scene once with plain arrays (rtmc_scene_desc), then
+ * asks for ranges of photon ids to be traced and receives additive tallies.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RTMC_E* code; the
+ *     text of the last failure of the calling thread is rtmc_last_error();
+ *   - nothing throws or aborts across this boundary;
+ *   - all pointers are host pointers; the library copies what it keeps;
+ *   - lengths in cm, wavelengths in nm, concentrations in mmol/L (the units
+ *     of the reference's job files);
+ *   - a scene handle is immutable after creation and may be used from several
+ *     host threads, one device each.
+ */
+#ifndef RTMC_H
+#define RTMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMC_ABI_VERSION 1
+
+/* error codes */
+#define RTMC_OK 0
+#define RTMC_EINVAL (-1)    /* malformed description or argument          */
+#define RTMC_EUNSUPPORTED (-2) /* feature of the reference not built yet  */
+#define RTMC_EDEVICE (-3)   /* HIP runtime failure                        */
+#define RTMC_ENOMEM (-4)
+#define RTMC_ELIMIT (-5)    /* scene exceeds a compiled-in limit          */
+
+/* geometry codes: index into the reference's `shapes` list, RayTrace.py:78 */
+#define RTMC_GEOM_RECTANGLE 1
+#define RTMC_GEOM_CIRCLE 2
+#define RTMC_GEOM_CYLINDER 3
+#define RTMC_GEOM_TRIANGLE 4
+/* element type codes: index into the reference's `types` list, RayTrace.py:79 */
+#define RTMC_TYPE_MIRROR 1
+#define RTMC_TYPE_INTERFACE 2
+#define RTMC_TYPE_LENS 3
+#define RTMC_TYPE_DUMP 4
+
+/* photon status codes (reference: the strings assigned to Photon.Status) */
+#define RTMC_ST_START 0
+#define RTMC_ST_ABSORBED 1
+#define RTMC_ST_REEMITTED_DONOR 2
+#define RTMC_ST_REEMITTED_ACCEPTOR 3
+#define RTMC_ST_INTERNAL_CONVERTED 4
+#define RTMC_ST_DUMPED 5
+#define RTMC_ST_LOST 6 /* no element found and none visited before (the reference raises) */
+
+/* number of 1-nm bins of a detector's incident spectrum, 200..3999 nm
+ * (reference Elements.py:143-144) */
+#define RTMC_SPECTRUM_BINS 3800
+#define RTMC_SPECTRUM_FIRST_NM 200
+
+/* One optical element = reference OpticalObject(Type, Geometry).
+ * Rectangle: Geometries.py:8-57.  `e1`/`e2` are the unit in-plane axes the
+ * reference derives in the constructor (Geometries.py:17-29, normalised at
+ * :40-41); `half1` pairs with e1 ("Height"), `half2` with e2 ("Width"). */
+typedef struct rtmc_element {
+    int32_t geometry;   /* RTMC_GEOM_*                                     */
+    int32_t type;       /* RTMC_TYPE_*                                     */
+    double support[3];  /* SupportVector                                   */
+    double normal[3];   /* DirectionVector, unit length                    */
+    double e1[3];
+    double e2[3];
+    double half1;
+    double half2;
+    int32_t material1;  /* Interface: MaterialSide1 (index into materials) */
+    int32_t material2;  /* Interface: MaterialSide2                        */
+    int32_t eqe_table;  /* Dump: index into `tables` of a detection
+                           spectrum (Elements.py:161-165), or -1           */
+    int32_t reserved;
+    double focal_length; /* Lens (Elements.py:117-132)                     */
+} rtmc_element;
+
+/* A two-column table (wavelength, value) stored as 2*len doubles,
+ * row-major, inside rtmc_scene_desc.table_data. */
+typedef struct rtmc_table {
+    int64_t offset; /* in doubles */
+    int64_t len;    /* rows       */
+} rtmc_table;
+
+/* One medium = reference Materials.MaterialObj after its constructor has
+ * processed the spectra (Materials.py:38-74).  `abs_*` are the cleaned,
+ * peak-normalised absorption tables, `em_*` the cleaned emission tables
+ * normalised to unit sum (NOT yet weighted by interval width). */
+typedef struct rtmc_material {
+    int32_t name_id;     /* materials that the reference would compare equal
+                            by name (Elements.py:45) share one id          */
+    int32_t is_absorber;
+    int32_t is_aligned;
+    int32_t fix_dist;
+    double n;            /* refractive index                               */
+    double conc_a, conc_b;
+    double emax_A, emax_D;
+    double Q_A, Q_D;
+    double tau_A, tau_D;
+    double fix_dist_R;
+    double align_vect[3];
+    double align_S;
+    double abs_em_angle;
+    double ol_DA, ol_AD; /* Foerster overlap sums (Materials.py:73-74)     */
+    double P_ET_DA, P_ET_AD; /* transfer probabilities
+                                (MonteCarloFRET.py:195-237)                */
+    rtmc_table abs_A, abs_D, em_A, em_D;
+} rtmc_material;
+
+/* Photon source = the constructor arguments of reference PhotonObject.Photon
+ * that GeneratePhoton uses (PhotonObject.py:61-97). */
+typedef struct rtmc_source {
+    int32_t direction_mode;  /* 0 "Directional Strict", 1 "Directional Isotropic" */
+    int32_t wavelength_mode; /* 0 fixed, 1 drawn from `spectrum`           */
+    double location[3];
+    double direction[3];     /* EmissionDirection as given (not normalised) */
+    double frame[9];         /* row-major 3x3; hemisphere sample d becomes
+                                d . frame (PhotonObject.py:71-72)          */
+    double wavelength;
+    rtmc_table spectrum;     /* sun table as read from file (before the
+                                x lambda and interval weighting of EmitSun,
+                                PhotonObject.py:39-46)                     */
+    int32_t start_material;
+    int32_t respect_polarization;
+    double scale_factor;
+} rtmc_source;
+
+typedef struct rtmc_scene_desc {
+    int32_t abi_version;     /* RTMC_ABI_VERSION                           */
+    int32_t n_elements;
+    int32_t n_materials;
+    int32_t n_tables;
+    const rtmc_element *elements;   /* list order is tie-break order       */
+    const rtmc_material *materials;
+    const rtmc_table *tables;       /* detector EQE tables                 */
+    const double *table_data;
+    int64_t table_data_len;         /* in doubles                          */
+    rtmc_source source;
+    int32_t max_iterations;  /* loop-iteration cap; the reference's
+                                `i >= 1e4` test allows 10001 (RayTrace.py:193) */
+    int32_t reserved;
+} rtmc_scene_desc;
+
+/* Additive results of tracing a range of photon ids.  The caller allocates
+ * the arrays (n_elements entries each; `spectrum` n_elements x
+ * RTMC_SPECTRUM_BINS, row per element, all zero for non-detectors) and zeroes
+ * them before the first call; every call ADDS to them.
+ * Mirrors: Dump.Counter / EnergyCounter / SpectralCounter / IncidentSpectrum
+ * (Elements.py:139-165), Mirror/Interface.BounceCounter (Elements.py:15,39),
+ * Photon.BeenAbsorbed[1] (RayTrace.py:197-198). */
+typedef struct rtmc_tallies {
+    int32_t n_elements;
+    int32_t reserved;
+    uint64_t n_photons;
+    uint64_t n_steps;          /* loop iterations executed                  */
+    uint64_t n_absorbed_once;  /* photons absorbed at least once            */
+    uint64_t n_absorptions;    /* absorption events                         */
+    uint64_t n_internal_converted;
+    uint64_t n_dumped;
+    uint64_t n_capped;         /* stopped by the iteration cap              */
+    uint64_t n_lost;           /* RTMC_ST_LOST                              */
+    uint64_t n_stale_steps;    /* iterations without a valid hit            */
+    uint64_t *counter;         /* per element                               */
+    uint64_t *spectral;        /* per element                               */
+    uint64_t *bounce;          /* per element                               */
+    uint64_t *energy_fx;       /* per element: sum of lambda_start/lambda in
+                                  units of 2^-24, rounded per photon        */
+    uint64_t *spectrum;        /* n_elements * RTMC_SPECTRUM_BINS           */
+} rtmc_tallies;
+#define RTMC_ENERGY_FX_SCALE 16777216.0
+
+/* Structure-of-arrays photon batch used by the step-wise entry point.
+ * Each pointer addresses `n` values.  Field meaning = the attributes of the
+ * reference's Photon object (PhotonObject.py:9-37) plus the two loop
+ * variables of RayTrace that outlive an iteration. */
+typedef struct rtmc_photon_soa {
+    double *loc[3];
+    double *dir[3];
+    double *efield[3];
+    double *old_point[3];   /* RayTrace.OldPoint                          */
+    double *wavelength;
+    double *start_wavelength;
+    double *dist_left;      /* DistanceLeftToAbsorption                   */
+    double *hit_distance;   /* out: SmallestDistance of the last iteration */
+    int32_t *material;
+    int32_t *status;        /* RTMC_ST_*                                  */
+    int32_t *last_element;  /* RayTrace.FirstEl as an index, -1 = none    */
+    int32_t *was_element;
+    int32_t *reflected;
+    int32_t *iterations;    /* loop iterations done so far                */
+    int32_t *tape_pos;      /* in/out: variates consumed from the tape    */
+} rtmc_photon_soa;
+
+typedef struct rtmc_scene rtmc_scene;
+
+/* precision of the device arithmetic */
+#define RTMC_F32 0 /* production path                                      */
+#define RTMC_F64 1 /* same kernels instantiated in double (validation)     */
+
+int rtmc_version(void);
+const char *rtmc_last_error(void);
+
+/* Replaces RayTrace.CreateOpticalElementList (RayTrace.py:70-114) and the
+ * photon-independent parts of the loop that the reference recomputes for
+ * every photon: RectifySpectrum + cumulative sums for the inverse-CDF draws
+ * (RTUtils.py:152-158, MonteCarloFRET.py:258-279), per-wavelength absorption
+ * coefficients (PhotonObject.py:288-289), nearest-bin lookups
+ * (RTUtils.py:15-22). */
+int rtmc_scene_create(const rtmc_scene_desc *desc, rtmc_scene **out);
+void rtmc_scene_destroy(rtmc_scene *scene);
+
+/* Replaces the photon loop of RayTrace.runSimulation (RayTrace.py:166-201)
+ * for photon ids [first_photon, first_photon + n_photons).  Variates come
+ * from Philox4x32-10 keyed by `seed` and counted by (photon id, draw event),
+ * so the result does not depend on how a job is split into calls or devices.
+ * Blocks until the tallies are on the host. */
+int rtmc_run(rtmc_scene *scene, int device, int precision, uint64_t seed,
+             uint64_t first_photon, uint64_t n_photons, rtmc_tallies *out);
+
+/* Device time of the trace kernel of the calling thread's last rtmc_run, in
+ * milliseconds, measured with HIP events on the stream the kernel ran on. */
+double rtmc_last_kernel_ms(const rtmc_scene *scene, int device);
+
+/* Replaces `n_steps` iterations of the loop body (RayTrace.py:178-195:
+ * CheckElementsForCrossingPoint, Photon.CheckForAbsorption, the element's
+ * ExecuteOperation) for `n` photons whose state the caller supplies.  The
+ * variates are not generated but read from `tape` in the order the reference
+ * consumes them (photon k uses tape[tape_off[k] + tape_pos[k] ...], never
+ * beyond tape_off[k+1]): uniforms where it calls rand()/choice(), standard
+ * normals for randn(), unit-scale exponentials for exponential().
+ * If `launch` is non-zero the photons are first generated as
+ * Photon.ResetPhoton does (PhotonObject.py:49-97) and the input state is
+ * ignored.  A photon that ends (Dumped, InternalConverted, cap) stops early.
+ * If `trace` is non-NULL it receives, per photon and iteration,
+ * RTMC_TRACE_STRIDE doubles (n * n_steps * RTMC_TRACE_STRIDE in all,
+ * photon-major; unused rows are left untouched). */
+#define RTMC_TRACE_STRIDE 16
+/* trace row: loc[3] dir[3] efield[3] wavelength dist_left status material
+ *            hit_element hit_distance tape_pos */
+int rtmc_step_tape(rtmc_scene *scene, int device, int precision, uint32_t n,
+                   rtmc_photon_soa *photons, const double *tape,
+                   const uint64_t *tape_off, uint32_t n_steps, int launch,
+                   double *trace);
+
+/* Per-operation entry points used for known-answer tests; each replaces one
+ * reference method on `n` independent inputs (arrays of n*3 doubles unless
+ * noted).  Geometry.FindIntersections for every element of the scene
+ * (Geometries.py:32-52): out_points is n * n_elements * 3, NaN where the
+ * reference returns [nan, nan, nan]. */
+int rtmc_op_intersect(rtmc_scene *scene, int device, int precision, uint32_t n,
+                      const double *loc, const double *dir, double *out_points);
+
+/* Number of wavelengths a photon can carry in this scene (source lines or
+ * table rows plus every emission-table row) and their values. */
+int rtmc_scene_wavelengths(const rtmc_scene *scene, int64_t *count, double *values,
+                           int64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMC_H */

@@ -1,0 +1,114 @@
+"""Job folders: reading the six `.prt` files and writing the result log.
+
+File names and layouts are those of the reference (IOOperation.py): a job is
+`Elements.prt`, `ElementProperties.prt`, `ElementGeometry.prt`,
+`ElementSize.prt`, `Materials.prt`, `Photon.prt`; `SaveLog` writes a
+time-stamped sub-folder with a copy of the job, `Logfile.txt`,
+`DetectorSpectrum<i>.txt` and `AbsorbedPhotons.txt`.  The files are decoded
+by `prt.py`, which never unpickles.
+"""
+from __future__ import annotations
+
+import copy
+import datetime
+import os
+
+import numpy as np
+
+from . import Materials, prt
+from . import PhotonObject as PhObj
+
+# position of each MaterialObj argument in a `Materials.prt` row
+# (reference IOOperation.py:81 / RayTracerGui.py:815)
+MATERIAL_ROW = ["name", "n", "IsAbsorber", "conc_b", "conc_a", "color", "IsAligned", "AlignVect",
+                "AlignS", "R_0", "Q_D", "Q_A", "tau_D", "tau_A", "emax_D", "emax_A", "sp_abs_D",
+                "sp_em_D", "sp_abs_A", "sp_em_A", "AbsEmAngle", "FixDist", "FixDistR",
+                "FixDistNeighbors"]
+
+
+class LoadSaveRT:
+    def __init__(self, Path, RayTracerInstance):
+        self.RTI = RayTracerInstance
+        self.ActivePath = Path
+        self.Materials = []
+
+    def LoadArrays(self):
+        job = prt.load_job(self.ActivePath)
+        self._take(job)
+
+    def _take(self, job):
+        self.Elements = np.array(job["Elements"], dtype=np.float64)
+        self.ElementProperties = copy.deepcopy(job["ElementProperties"])
+        self.ElementGeometry = list(job["ElementGeometry"])
+        self.ElementSize = copy.deepcopy(job["ElementSize"])
+        self.Materials = copy.deepcopy(job["Materials"])
+        self.PhArray = copy.deepcopy(job["Photon"])
+
+    def ParsePath(self, Path):
+        """Read a job folder and rebuild the tracer's scene from it
+        (reference IOOperation.py:73-115)."""
+        self.ActivePath = Path
+        self.LoadArrays()
+        self._build()
+
+    def ParseJob(self, job):
+        """Same as ParsePath for a job already in memory."""
+        self._take(job)
+        self._build()
+
+    def _build(self):
+        rti = self.RTI
+        for row in self.Materials:
+            if row[0] not in rti.MaterialDict:
+                rti.MaterialDict[row[0]] = Materials.MaterialObj(**dict(zip(MATERIAL_ROW, row)))
+        props = []
+        for p in self.ElementProperties:
+            if p[0] == 2:
+                props.append([2, rti.MaterialDict[p[1]], rti.MaterialDict[p[2]]])
+            elif p[0] == 4:
+                eqe = 1 if p[3] == "" else Materials.load_table(p[3])
+                props.append([4, 0, 0, 0, eqe])
+            else:
+                props.append(list(p))
+        rti.Elements = self.Elements
+        rti.ElementGeometry = self.ElementGeometry
+        rti.ElementSize = self.ElementSize
+        rti.ElementProperties = props
+        ph = self.PhArray
+        rti.PhArray = ph
+        rti.NumberOfPhotons = ph[0]
+        rti.Photon = PhObj.Photon(Location=ph[1], EmissionMode=ph[2], EmissionDirection=ph[6],
+                                  EmissionWavelengthType=ph[3], StartingWavelength=ph[4],
+                                  StartingMaterial=rti.MaterialDict[ph[5]],
+                                  RespectPolarization=ph[7], StartingLocation=ph[1],
+                                  ScaleFactor=ph[8] if len(ph) == 9 else 1.0)
+        rti.lineclr = rti.Photon.StartingMaterial.color
+        rti.CreateOpticalElementList()
+
+    def SaveLog(self):
+        """Write the job copy and the results (reference IOOperation.py:34-69):
+        `Logfile.txt` rows are [Counter, EnergyCounter, SpectralCounter,
+        BounceCounter] per element."""
+        stamp = datetime.datetime.now().strftime("%Y-%m-%d_%Hh%Mm%Ss")
+        folder = os.path.join(self.ActivePath, stamp)
+        os.makedirs(folder, exist_ok=True)
+        rti = self.RTI
+        prt.dump_job(folder, {"Elements": rti.Elements,
+                              "ElementProperties": rti.ElementProperties,
+                              "ElementGeometry": rti.ElementGeometry,
+                              "ElementSize": rti.ElementSize,
+                              "Materials": self.Materials, "Photon": rti.PhArray})
+        log = np.zeros((len(rti.OpticalElements), 4))
+        for i, oe in enumerate(rti.OpticalElements):
+            typ = oe.Type
+            if typ.kind == "Dump":
+                log[i, :3] = [typ.Counter, typ.EnergyCounter, typ.SpectralCounter]
+                np.savetxt(os.path.join(folder, "DetectorSpectrum%d.txt" % i),
+                           typ.IncidentSpectrum)
+            else:
+                log[i, 3] = typ.BounceCounter
+        np.savetxt(os.path.join(folder, "Logfile.txt"), log)
+        np.savetxt(os.path.join(folder, "AbsorbedPhotons.txt"),
+                   np.array([rti.Photon.BeenAbsorbed[1]]))
+        self.LastLogFolder = folder
+        return folder

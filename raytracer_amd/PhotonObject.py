@@ -1,0 +1,60 @@
+"""Photon source description and single-photon state view (host side).
+
+In the reference one mutable `Photon` object is the photon: it is re-launched
+N times and every element mutates it (PhotonObject.py).  On the device a
+photon is a row of a structure-of-arrays batch; this class keeps the
+constructor signature (PhotonObject.py:9) so that job parsing and user
+scripts work unchanged, stores the launch parameters the kernels need, and
+exposes the state attributes for single-photon inspection through
+`RayTrace.TraceTape`.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import configs
+
+SUN = "Sun spectrum AG15g"
+ISOTROPIC = "Directional Isotropic"
+STRICT = "Directional Strict"
+
+
+class Photon:
+    def __init__(self, Location=[0, 0, 0], EmissionMode=ISOTROPIC, EmissionDirection=[0, 0, 0],
+                 EmissionWavelengthType=SUN, StartingWavelength=450.0, StartingMaterial=None,
+                 RespectPolarization=True, StartingLocation=[0, 0, 0], ScaleFactor=1.0):
+        self.Location = Location
+        self.EmissionMode = EmissionMode
+        self.EmissionDirection = EmissionDirection
+        self.EmissionWavelengthType = EmissionWavelengthType
+        self.StartingWavelength = StartingWavelength
+        self.StartingMaterial = StartingMaterial
+        self.RespectPolarization = RespectPolarization
+        self.StartingLocation = StartingLocation
+        self.ScaleFactor = ScaleFactor
+        # state attributes of the reference object (PhotonObject.py:21-37)
+        self.PointCy = [0, 0, 0]
+        self.OperationPlane = [[0, 0, 0], [0, 0, 0]]
+        self.WasElement = False
+        self.BeenAbsorbed = [False, 0]
+        self.sgn = 1
+        self.Reflected = False
+        self.Psi = 0
+        self.Direction = np.array([0.0, 0.0, 1.0])
+        self.CurrentMaterial = StartingMaterial
+        self.Status = "Start"
+        self.Wavelength = 450.0
+        self.DistanceLeftToAbsorption = 0.0
+        self.ElectricFieldVector = [1, 0, 0]
+        self.OldPoint = [0, 0, 0]
+        self.LineColor = "black"
+
+    def sun_table(self):
+        """Two-column sun spectrum used when the wavelength type is the sun
+        spectrum: `AM15.txt` from the working directory as the reference
+        reads it (PhotonObject.py:41), else the packaged black-body stand-in."""
+        if os.path.isfile("AM15.txt"):
+            return np.loadtxt("AM15.txt")
+        return configs.synthetic_am15()

@@ -1,0 +1,160 @@
+"""Job definitions for the benchmark / parity configurations.
+
+Every function returns a *job*: a dict with the six arrays of a `.prt` job
+folder in exactly the layout the reference's GUI writes and
+`IOOperation.LoadSaveRT.LoadArrays` reads (reference IOOperation.py:19-31,
+field order of a material row at IOOperation.py:81, of the photon list at
+IOOperation.py:100-109).  Units: cm, nm, mmol/L.
+
+The same dicts feed three consumers: `prt.dump_job` (to write a job folder),
+`RayTrace.RayTrace.LoadJob` (the host mirror) and the golden-vector generator
+that runs the reference itself.
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+AIR_ROW = ["air", 1.0, False, 0.0, 0.0, "blue", False, [0.0, 0.0, 0.0], 0.0, 0.0, 0.0, 0.0,
+           0.0, 0.0, 0.0, 0.0, "0", "0", "0", "0", 0, False, 0.0, 1]
+
+
+def dye_row(name, conc_a=1.0, conc_b=0.0, n=1.5, aligned=False, align_s=0.1,
+            align_vect=(0.0, 0.0, 1.0), abs_em_angle=0):
+    """Material row: Lumogen Red acceptor (+ optional Oxacin donor)."""
+    return [name, float(n), True, float(conc_b), float(conc_a), "red", bool(aligned),
+            [float(c) for c in align_vect], float(align_s), 5.0,
+            0.9, 0.95, 2.5, 6.0, 35731.0, 54000.0,
+            "OxacinAbs.txt", "OxacinEm.txt", "LumogenRedAbs.txt", "LumogenRedEm.txt",
+            abs_em_angle, False, 1.0, 1]
+
+
+def _slab_faces(z0, z1, half, mat, edge_types=(4, 4, 4, 4)):
+    """Six rectangles of one slab: bottom/top interfaces then the four edges.
+
+    Order and orientation follow the shipped job (bottom `[mat, air]`, top
+    `[air, mat]`, edges at +x, -x, +y, -y with inward normals)."""
+    zc = 0.5 * (z0 + z1)
+    hw = 0.5 * (z1 - z0)
+    elements = [
+        [[0.0, 0.0, z0], [0.0, 0.0, 1.0]],
+        [[0.0, 0.0, z1], [0.0, 0.0, 1.0]],
+        [[half, 0.0, zc], [-1.0, 0.0, 0.0]],
+        [[-half, 0.0, zc], [1.0, 0.0, 0.0]],
+        [[0.0, half, zc], [0.0, -1.0, 0.0]],
+        [[0.0, -half, zc], [0.0, 1.0, 0.0]],
+    ]
+    props = [[2, mat, "air"], [2, "air", mat]]
+    for t in edge_types:
+        props.append([4, 0, 0, ""] if t == 4 else [1])
+    sizes = [[half, half], [half, half]] + [[half, hw]] * 4
+    return elements, props, [list(s) for s in sizes]
+
+
+def _dump_box(cx, cy, zc, hx, hz):
+    """Closed box of six detector rectangles written out explicitly."""
+    elements = [
+        [[cx + hx, cy, zc], [1.0, 0.0, 0.0]],
+        [[cx - hx, cy, zc], [-1.0, 0.0, 0.0]],
+        [[cx, cy + hx, zc], [0.0, 1.0, 0.0]],
+        [[cx, cy - hx, zc], [0.0, -1.0, 0.0]],
+        [[cx, cy, zc + hz], [0.0, 0.0, 1.0]],
+        [[cx, cy, zc - hz], [0.0, 0.0, -1.0]],
+    ]
+    props = [[4, 0, 0, ""] for _ in range(6)]
+    sizes = [[hx, hz], [hx, hz], [hx, hz], [hx, hz], [hx, hx], [hx, hx]]
+    return elements, props, sizes
+
+
+def _photon(n, start, mode, wl_type, wl, mat, direction, respect_pol=True, scale=1.0):
+    return [int(n), [float(c) for c in start], mode, wl_type, wl, mat,
+            [float(c) for c in direction], bool(respect_pol), float(scale)]
+
+
+STRICT = "Directional Strict"
+ISOTROPIC = "Directional Isotropic"
+FIXED_WL = "Specified Wavelength..."
+SUN = "Sun spectrum AG15g"
+
+
+def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=False,
+             aligned=False, align_s=0.1):
+    """One 5 x 5 cm dye-doped slab, source at (0, 2, 1) pointing down at 460 nm.
+
+    thickness 0.012 + enclosed False is the shipped job's geometry."""
+    name = "LRO" if donor else "LR"
+    els, props, sizes = _slab_faces(0.0, thickness, 2.5, name)
+    if enclosed:
+        zc = 0.5 * thickness
+        e2, p2, s2 = _dump_box(0.0, 0.0, zc, 4.0, 2.0)
+        els, props, sizes = els + e2, props + p2, sizes + s2
+    mats = [copy.deepcopy(AIR_ROW),
+            dye_row(name, conc_a=1.0, conc_b=1.0 if donor else 0.0, aligned=aligned,
+                    align_s=align_s)]
+    photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460,
+                     "air", (0.0, 0.0, -1.0))
+    return {
+        "Elements": np.array(els, dtype=np.float64),
+        "ElementProperties": props,
+        "ElementGeometry": [1] * len(els),
+        "ElementSize": sizes,
+        "Materials": mats,
+        "Photon": photon,
+    }
+
+
+def stacked_job(n_photons=10000):
+    """Three stacked slabs (0.3 thick, 0.05 air gaps); each slab has mirrors on
+    three edges and a detector on the +x edge; isotropic source above; closed
+    detector box around everything.  Element order: slab 1 (top), slab 2,
+    slab 3, box."""
+    els, props, sizes = [], [], []
+    tops = [0.7, 0.35, 0.0]
+    names = ["LR", "LRO", "LR"]
+    for z0, nm in zip(tops, names):
+        e, p, s = _slab_faces(z0, z0 + 0.3, 2.5, nm, edge_types=(4, 1, 1, 1))
+        els, props, sizes = els + e, props + p, sizes + s
+    e, p, s = _dump_box(0.0, 0.0, 0.5, 4.0, 2.0)
+    els, props, sizes = els + e, props + p, sizes + s
+    mats = [copy.deepcopy(AIR_ROW), dye_row("LR"), dye_row("LRO", conc_b=1.0)]
+    photon = _photon(n_photons, (0.0, 0.0, 2.0), ISOTROPIC, FIXED_WL, 460, "air",
+                     (0.0, 0.0, -1.0))
+    return {
+        "Elements": np.array(els, dtype=np.float64),
+        "ElementProperties": props,
+        "ElementGeometry": [1] * len(els),
+        "ElementSize": sizes,
+        "Materials": mats,
+        "Photon": photon,
+    }
+
+
+def synthetic_am15():
+    """Two-column stand-in for the sun table the reference expects in
+    `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with
+    it): spectral irradiance of a 5778 K black body, 300..1100 nm in 1 nm
+    steps, normalised to a peak of 1."""
+    lam = np.arange(300.0, 1101.0, 1.0)
+    x = 1.4387769e7 / (lam * 5778.0)      # hc/(lambda k T), lambda in nm
+    irr = lam ** -5.0 / np.expm1(x)
+    return np.stack([lam, irr / irr.max()], axis=1)
+
+
+CONFIGS = {
+    # name: (builder, kwargs)
+    "C1_open": (slab_job, dict(thickness=0.012, enclosed=False)),
+    "C1": (slab_job, dict(thickness=0.012, enclosed=True)),
+    "C2": (slab_job, dict(thickness=0.3, enclosed=True)),
+    "C3": (slab_job, dict(thickness=0.3, enclosed=True, donor=True)),
+    "C4": (stacked_job, dict()),
+    "C5": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, sun=True)),
+}
+
+
+def make_job(name, n_photons=None):
+    builder, kwargs = CONFIGS[name]
+    kwargs = dict(kwargs)
+    if n_photons is not None:
+        kwargs["n_photons"] = n_photons
+    return builder(**kwargs)

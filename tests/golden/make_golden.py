@@ -1,0 +1,559 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it
+writes are what travels.  The reference is Python 2, so each run makes a
+throw-away `lib2to3` translation of its modules in a temporary directory
+outside the repository, imports that, and deletes it afterwards.  Nothing of
+the reference's text is written into the repository: the outputs are numbers
+(draw tapes, per-iteration photon states, processed spectra, tallies).
+
+Harness-side shims (none touches the physics):
+  * `builtins.__builtin__` alias (the translated Materials module still
+    writes to `__builtin__`);
+  * `np.shape` tolerant of the ragged demo lists printed by the constructor;
+  * `RTUtils.MakeBox` re-stated with integer index `i // 2` (Python-2 `/`);
+  * drawing replaced by a recorder object, `SaveLog` by a no-op;
+  * `np.random.{rand,randn,exponential,choice}` wrapped so that every variate
+    is recorded; the wrappers consume the legacy MT19937 stream exactly like
+    the originals (`exponential(scale)` = `scale * standard_exponential()`,
+    `choice(a, p=p)` = one `random_sample()` + `searchsorted(cdf, u, 'right')`),
+    so a wrapped run and an unwrapped run with the same seed are identical.
+
+usage:  python tests/golden/make_golden.py traces|tallies|materials|kat|all
+"""
+from __future__ import annotations
+
+import builtins
+import contextlib
+import importlib
+import io
+import json
+import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+sys.path.insert(0, REPO)
+
+from raytracer_amd import configs  # noqa: E402
+
+REF_MODULES = ["RayTrace", "PhotonObject", "Elements", "Geometries", "RTUtils", "Materials",
+               "MonteCarloFRET", "IOOperation", "OpticalObject", "DrawGraph"]
+STATUS_CODES = {"Start": 0, "Absorbed": 1, "ReemittedDonor": 2, "ReemittedAcceptor": 3,
+                "InternalConverted": 4, "Dumped": 5}
+
+
+# ---------------------------------------------------------------------------
+# scratch translation
+# ---------------------------------------------------------------------------
+
+class Reference:
+    """Imports a scratch py3 translation of the reference and applies the shims."""
+
+    def __init__(self):
+        self.tmp = tempfile.mkdtemp(prefix="rt_ref_")
+        self.src = os.path.join(self.tmp, "src")
+        self.data = os.path.join(self.tmp, "data")
+        os.makedirs(self.src)
+        os.makedirs(self.data)
+        for m in REF_MODULES:
+            shutil.copy(os.path.join(REFERENCE, m + ".py"), self.src)
+        subprocess.run([sys.executable, "-m", "lib2to3", "-w", "-n", self.src],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in os.listdir(REFERENCE):
+            if f.endswith(".txt") and f != "requirements.txt":
+                shutil.copy(os.path.join(REFERENCE, f), self.data)
+        np.savetxt(os.path.join(self.data, "AM15.txt"), configs.synthetic_am15())
+        os.environ["MPLBACKEND"] = "Agg"
+        builtins.__builtin__ = builtins
+        self._orig_shape = np.shape
+        np.shape = self._tolerant_shape
+        sys.path.insert(0, self.src)
+        os.chdir(self.data)
+        with contextlib.redirect_stdout(io.StringIO()):
+            self.mod = {m: importlib.import_module(m) for m in REF_MODULES}
+        self.mod["RTUtils"].MakeBox = self._make_box
+        self.mod["DrawGraph"].DrawElements = _DrawRecorder
+        self.mod["IOOperation"].LoadSaveRT.SaveLog = lambda self_: None
+        self.rec = DrawRecorder()
+
+    def _tolerant_shape(self, a):
+        try:
+            return self._orig_shape(a)
+        except ValueError:
+            return (len(a),)
+
+    def _make_box(self, M=[0, 0, 0], Size=[0.2, 0.2, 0.2], n_x=[1, 0, 0]):
+        rtu = self.mod["RTUtils"]
+        faces = np.array([[[0.0, 0, 0], [s * (k == 0), s * (k == 1), s * (k == 2)]]
+                          for k in range(3) for s in (1.0, -1.0)])
+        n_x = np.asarray(n_x, dtype=float)
+        n_x /= np.linalg.norm(n_x)
+        tm = rtu.MakeVectAxis(n_x)
+        size = np.asarray(Size, dtype=float)
+        for i in range(6):
+            nv = tm.dot(faces[i][1])
+            faces[i][1] = nv / np.linalg.norm(nv)
+            faces[i][0] = np.asarray(M) + faces[i][1] * size[i // 2]
+        return faces
+
+    def close(self):
+        np.shape = self._orig_shape
+        os.chdir(REPO)
+        shutil.rmtree(self.tmp, ignore_errors=True)
+
+    # -- job handling -----------------------------------------------------
+    def load_job(self, job, quiet=True):
+        """RayTrace() + ParsePath on a job dict (written as py3 pickles in the scratch dir)."""
+        folder = tempfile.mkdtemp(prefix="job_", dir=self.tmp)
+        for name in ("Elements", "ElementProperties", "ElementGeometry", "ElementSize",
+                     "Materials", "Photon"):
+            with open(os.path.join(folder, name + ".prt"), "wb") as fh:
+                pickle.dump(job[name], fh, protocol=2)
+        out = io.StringIO() if quiet else sys.stdout
+        with contextlib.redirect_stdout(out):
+            rt = self.mod["RayTrace"].RayTrace()
+            rt.IOOperator.ParsePath(folder)
+        return rt
+
+
+class _DrawRecorder:
+    """Stand-in for DrawGraph.DrawElements; DrawLine is the per-iteration hook."""
+    hook = None
+
+    def __init__(self, elements):
+        pass
+
+    def DrawElementsPoly(self):
+        pass
+
+    def DrawLine(self, p0, p1, color):
+        if _DrawRecorder.hook is not None:
+            _DrawRecorder.hook()
+
+    def DrawPoint(self, *a):
+        pass
+
+
+class DrawRecorder:
+    """Wraps the four `np.random` entry points the reference uses."""
+
+    def __init__(self):
+        self.tape: list = []
+        self.kinds: list = []
+        self.enabled = False
+        self._rand, self._randn = np.random.rand, np.random.randn
+        self._exp, self._choice = np.random.exponential, np.random.choice
+        np.random.rand = self.rand
+        np.random.randn = self.randn
+        np.random.exponential = self.exponential
+        np.random.choice = self.choice
+
+    def _log(self, kind, values):
+        if self.enabled:
+            for v in np.atleast_1d(values):
+                self.tape.append(float(v))
+                self.kinds.append(kind)
+
+    def rand(self, *shape):
+        v = self._rand(*shape)
+        self._log(0, v)
+        return v
+
+    def randn(self, *shape):
+        v = self._randn(*shape)
+        self._log(1, v)
+        return v
+
+    def exponential(self, scale=1.0, size=None):
+        assert size is None
+        e = np.random.standard_exponential()
+        self._log(2, e)
+        return scale * e
+
+    def choice(self, a, size=None, replace=True, p=None):
+        p = np.asarray(p, dtype=np.float64)
+        cdf = p.cumsum()
+        cdf /= cdf[-1]
+        u = np.random.random_sample()
+        self._log(0, u)
+        idx = int(cdf.searchsorted(u, side="right"))
+        pop = np.arange(a) if np.isscalar(a) else np.asarray(a)
+        if size is None:
+            return pop[idx]
+        return np.array([pop[idx]])
+
+
+# ---------------------------------------------------------------------------
+# runs
+# ---------------------------------------------------------------------------
+
+def collect_tallies(rt):
+    n_el = len(rt.OpticalElements)
+    elements_mod = type(rt.OpticalElements[0].Type).__module__
+    out = {"counter": [0] * n_el, "energy": [0.0] * n_el, "spectral": [0] * n_el,
+           "bounce": [0] * n_el, "absorbed_once": int(rt.Photon.BeenAbsorbed[1])}
+    hist = {}
+    for i, oe in enumerate(rt.OpticalElements):
+        t = oe.Type
+        if type(t).__name__ == "Dump":
+            out["counter"][i] = int(t.Counter)
+            out["energy"][i] = float(t.EnergyCounter)
+            out["spectral"][i] = int(t.SpectralCounter)
+            nz = np.nonzero(t.IncidentSpectrum[:, 1])[0]
+            hist[str(i)] = {str(int(t.IncidentSpectrum[k, 0])): int(t.IncidentSpectrum[k, 1])
+                            for k in nz}
+        else:
+            out["bounce"][i] = int(t.BounceCounter)
+    out["hist"] = hist
+    return out
+
+
+def run_traced(ref, job, seed, n_photons, max_iter_store=400):
+    """Run `n_photons` and record, per photon, the draw tape and the state after
+    every loop iteration (reference RayTrace.py:178-195)."""
+    rt = ref.load_job(job)
+    rt.NumberOfPhotons = n_photons
+    rec = ref.rec
+    mats = list(rt.MaterialDict.keys())
+    photons = []
+    cur = {}
+    fates = {"ic": 0, "capped": 0, "steps": 0, "stale": 0}
+
+    photon_cls = ref.mod["PhotonObject"].Photon
+    orig_reset = photon_cls.ResetPhoton
+    orig_check = type(rt).CheckElementsForCrossingPoint
+
+    def reset_hook(self_, plane):
+        if cur:
+            photons.append(dict(cur))
+        cur.clear()
+        cur["tape_start"] = len(rec.tape)
+        cur["rows"] = []
+        orig_reset(self_, plane)
+        cur["init"] = _state_row(rt, mats, -1, np.nan, len(rec.tape))
+
+    def check_hook(self_):
+        orig_check(self_)
+        cur["hit"] = (self_.OpticalElements.index(self_.FirstEl)
+                      if hasattr(self_, "FirstEl") else -1)
+        cur["dist"] = float(self_.SmallestDistance)
+        if not np.isfinite(self_.SmallestDistance):
+            fates["stale"] += 1
+
+    def line_hook():
+        fates["steps"] += 1
+        if len(cur["rows"]) < max_iter_store:
+            cur["rows"].append(_state_row(rt, mats, cur["hit"], cur["dist"], len(rec.tape)))
+        cur["n_iter"] = cur.get("n_iter", 0) + 1
+        cur["final_status"] = rt.Photon.Status
+
+    photon_cls.ResetPhoton = reset_hook
+    type(rt).CheckElementsForCrossingPoint = check_hook
+    _DrawRecorder.hook = line_hook
+    rec.tape.clear()
+    rec.kinds.clear()
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            np.random.seed(seed)
+            rec.enabled = True
+            rt.runSimulation()
+            rec.enabled = False
+    finally:
+        photon_cls.ResetPhoton = orig_reset
+        type(rt).CheckElementsForCrossingPoint = orig_check
+        _DrawRecorder.hook = None
+    photons.append(dict(cur))
+    for p in photons:
+        if p["final_status"] == "InternalConverted":
+            fates["ic"] += 1
+        elif p["final_status"] != "Dumped":
+            fates["capped"] += 1
+    return rt, photons, np.array(rec.tape), fates
+
+
+def _state_row(rt, mats, hit, dist, tape_pos):
+    ph = rt.Photon
+    old = np.asarray(rt.OldPoint, dtype=float) if hasattr(rt, "OldPoint") else np.zeros(3)
+    return np.concatenate([
+        np.asarray(ph.Location, dtype=float), np.asarray(ph.Direction, dtype=float),
+        np.asarray(ph.ElectricFieldVector, dtype=float),
+        [float(ph.Wavelength), float(ph.DistanceLeftToAbsorption),
+         float(STATUS_CODES[ph.Status]), float(mats.index(ph.CurrentMaterial.name)),
+         float(hit), float(dist), float(bool(ph.WasElement)), float(bool(ph.Reflected)),
+         float(ph.sgn), float(tape_pos)],
+        old])
+
+
+ROW_FIELDS = ["Lx", "Ly", "Lz", "Dx", "Dy", "Dz", "Ex", "Ey", "Ez", "wavelength", "dist_left",
+              "status", "material", "hit_element", "hit_distance", "was_element", "reflected",
+              "sgn", "tape_pos", "OldPx", "OldPy", "OldPz"]
+
+
+def pack_traces(photons, tape):
+    """Flatten per-photon rows into arrays for an .npz."""
+    rows, row_off, tape_off, n_iter, init = [], [0], [], [], []
+    for p in photons:
+        rows.extend(p["rows"])
+        row_off.append(len(rows))
+        tape_off.append(p["tape_start"])
+        n_iter.append(p["n_iter"])
+        init.append(p["init"])
+    tape_off.append(len(tape))
+    return dict(rows=np.array(rows), row_off=np.array(row_off), tape=tape,
+                tape_off=np.array(tape_off), n_iter=np.array(n_iter), init=np.array(init),
+                fields=np.array(ROW_FIELDS))
+
+
+def gen_traces(ref):
+    plan = {"C1_open": (40, 11, 150), "C1": (60, 12, 400), "C2": (120, 13, 400),
+            "C3": (160, 14, 400), "C4": (120, 15, 400), "C5": (120, 16, 400)}
+    for name, (n, seed, cap) in plan.items():
+        job = configs.make_job(name, n_photons=n)
+        t0 = time.time()
+        rt, photons, tape, fates = run_traced(ref, job, seed, n, max_iter_store=cap)
+        packed = pack_traces(photons, tape)
+        packed["tallies_json"] = np.array(json.dumps(collect_tallies(rt)))
+        packed["fates_json"] = np.array(json.dumps(fates))
+        np.savez_compressed(os.path.join(HERE, "trace_%s.npz" % name), **packed)
+        print(name, "photons", n, "rows", len(packed["rows"]), "tape", len(tape), fates,
+              "%.1fs" % (time.time() - t0), flush=True)
+
+
+def gen_materials(ref):
+    """Processed spectra and Foerster constants as the reference computes them."""
+    out = {}
+    for name in ("C2", "C3"):
+        rt = ref.load_job(configs.make_job(name, n_photons=1))
+        for mname, m in rt.MaterialDict.items():
+            if not m.IsAbsorber:
+                continue
+            key = name + "_" + mname
+            for tab in ("sp_abs_D", "sp_em_D", "sp_abs_A", "sp_em_A"):
+                out[key + "_" + tab] = np.asarray(getattr(m, tab))
+            out[key + "_ol"] = np.array([m.ol_DA, m.ol_AD])
+            with contextlib.redirect_stdout(io.StringIO()):
+                rt.Photon.CurrentMaterial = m
+                fret = ref.mod["MonteCarloFRET"].MCFRET(rt.Photon, True, True)
+                fret.GenerateMolecules()
+            out[key + "_pet"] = np.array([fret.P_ET_DA, fret.P_ET_AD])
+            rtu = ref.mod["RTUtils"]
+            out[key + "_rect_em_A"] = rtu.RectifySpectrum(m.sp_em_A)
+            out[key + "_rect_em_D"] = rtu.RectifySpectrum(m.sp_em_D)
+    np.savez_compressed(os.path.join(HERE, "materials.npz"), **out)
+    print("materials:", sorted(out))
+
+
+def gen_kat(ref):
+    """Known-answer vectors pinned by the reference's own unit tests, plus
+    direct calls of single operations on random inputs."""
+    geo, els, pho = ref.mod["Geometries"], ref.mod["Elements"], ref.mod["PhotonObject"]
+    rtu = ref.mod["RTUtils"]
+    rng = np.random.RandomState(7)
+    out = {}
+
+    class P:  # minimal photon carrier for Geometry calls
+        pass
+
+    # TestGeometries.py:22-70
+    ph = P()
+    rect = geo.Rectangle(1.5, 2.5, np.array([1.0, 2.0, 3.0]), np.array([0.0, 1.0, 0.0]), ph,
+                         [0.0, 0.0, 0.0])
+    ph.Location, ph.Direction = np.array([0.0, -2.0, 2.0]), np.array([2.0, 2.0, 0.0])
+    out["kat_rect_miss"] = np.asarray(rect.FindIntersections(), dtype=float)
+    ph.Direction = np.array([0.2, 2.0, 0.1])
+    out["kat_rect_hit"] = np.asarray(rect.FindIntersections(), dtype=float)
+    rect2 = geo.Rectangle(1.5, 2.5, np.array([1.0, 2.0, 3.0]), np.array([0.0, 1.0, 0.0]), ph,
+                          list(np.cross([0.0, 1.0, 0.0], [1, 2, 3])))
+    out["kat_rect_hit_axis"] = np.asarray(rect2.FindIntersections(), dtype=float)
+
+    # random rectangles / rays
+    n = 256
+    S = rng.uniform(-2, 2, (n, 3)); N = rng.normal(size=(n, 3))
+    L = rng.uniform(-3, 3, (n, 3)); D = rng.normal(size=(n, 3))
+    H = rng.uniform(0.5, 3, n); W = rng.uniform(0.5, 3, n)
+    hits = np.zeros((n, 3)); e1 = np.zeros((n, 3)); e2 = np.zeros((n, 3)); nn = np.zeros((n, 3))
+    for i in range(n):
+        r = geo.Rectangle(H[i], W[i], S[i].copy(), N[i].copy(), ph, [0, 0, 0])
+        ph.Location, ph.Direction = L[i].copy(), D[i].copy()
+        hits[i] = np.asarray(r.FindIntersections(), dtype=float)
+        e1[i], e2[i], nn[i] = r.e1, r.e2, r.DirectionVector
+    out.update(rect_S=S, rect_N=N, rect_L=L, rect_D=D, rect_H=H, rect_W=W, rect_hit=hits,
+               rect_e1=e1, rect_e2=e2, rect_n=nn)
+
+    # interface operations on random unit directions / polarisations
+    with contextlib.redirect_stdout(io.StringIO()):
+        air = ref.mod["Materials"].MaterialObj("kat_air", 1.0)
+        glass = ref.mod["Materials"].MaterialObj("kat_glass", 1.5)
+    m = 512
+    Dn = rng.normal(size=(m, 3)); Dn /= np.linalg.norm(Dn, axis=1)[:, None]
+    En = np.cross(Dn, rng.normal(size=(m, 3))); En /= np.linalg.norm(En, axis=1)[:, None]
+    Pn = rng.normal(size=(m, 3)); Pn /= np.linalg.norm(Pn, axis=1)[:, None]
+    Sp = rng.uniform(-1, 1, (m, 3)); Lp = rng.uniform(-1, 1, (m, 3))
+    inside = rng.rand(m) < 0.5
+    res = np.zeros((m, 12))
+    refl = np.zeros((m, 9))
+    for i in range(m):
+        photon = pho.Photon(StartingMaterial=air)
+        photon.Location, photon.Direction = Lp[i].copy(), Dn[i].copy()
+        photon.ElectricFieldVector = En[i].copy()
+        photon.OperationPlane = [Sp[i].copy(), Pn[i].copy()]
+        photon.CurrentMaterial = glass if inside[i] else air
+        iface = els.Interface(air, glass, photon)
+        photon.PrepareExecution()
+        n1, n2 = (1.5, 1.0) if inside[i] else (1.0, 1.5)
+        tir = iface.IsTotalReflect(n1, n2)
+        with np.errstate(all="ignore"):
+            R = iface.Reflectance(n1, n2)
+        # refract branch
+        pr = pho.Photon(StartingMaterial=air)
+        pr.Location, pr.Direction = Lp[i].copy(), Dn[i].copy()
+        pr.ElectricFieldVector = En[i].copy()
+        pr.OperationPlane = [Sp[i].copy(), Pn[i].copy()]
+        pr.PrepareExecution()
+        with np.errstate(all="ignore"):
+            pr.RefractOnPlane(n1, n2)
+            pr.PostProcessExecution()
+        # reflect branch
+        pm = pho.Photon(StartingMaterial=air)
+        pm.Location, pm.Direction = Lp[i].copy(), Dn[i].copy()
+        pm.ElectricFieldVector = En[i].copy()
+        pm.OperationPlane = [Sp[i].copy(), Pn[i].copy()]
+        pm.PrepareExecution()
+        pm.ReflectOnPlane()
+        pm.PostProcessExecution()
+        res[i] = np.concatenate([[float(tir), R, photon.sgn], pr.Location, pr.Direction,
+                                 pr.ElectricFieldVector])
+        refl[i] = np.concatenate([pm.Location, pm.Direction, pm.ElectricFieldVector])
+    out.update(if_D=Dn, if_E=En, if_n=Pn, if_S=Sp, if_L=Lp, if_inside=inside, if_res=res,
+               if_refl=refl)
+
+    # sample values quoted for air -> n=1.5 at 0.5 rad
+    photon = pho.Photon(StartingMaterial=air)
+    photon.Direction = np.array([np.sin(0.5), 0.0, -np.cos(0.5)])
+    photon.Location = np.array([0.0, 0.0, 1.0])
+    photon.OperationPlane = [np.zeros(3), np.array([0.0, 0.0, 1.0])]
+    photon.ElectricFieldVector = np.array([0.0, 1.0, 0.0])
+    iface = els.Interface(air, glass, photon)
+    photon.PrepareExecution()
+    out["kat_Rs_05"] = np.array([iface.Reflectance(1.0, 1.5)])
+    photon.ElectricFieldVector = np.array([np.cos(0.5), 0.0, np.sin(0.5)])
+    out["kat_Rp_05"] = np.array([iface.Reflectance(1.0, 1.5)])
+    photon.RefractOnPlane(1.0, 1.5)
+    out["kat_refr_05"] = np.asarray(photon.Direction, dtype=float)
+
+    # nearest-neighbour lookup
+    A = np.sort(np.concatenate([rng.uniform(300, 700, 60), [400.0, 400.0, 500.0]]))
+    T = np.concatenate([rng.uniform(250, 750, 200), A[:10], [A[0] - 5, A[-1] + 5]])
+    out["fc_A"], out["fc_T"] = A, T
+    out["fc_idx"] = np.array([int(rtu.FindClosestListElement(A, t)) for t in T])
+
+    # CheckSides
+    v1 = rng.uniform(-1, 1, (200, 3)); v2 = rng.uniform(-1, 1, (200, 3))
+    pl = rng.uniform(-1, 1, (200, 2, 3))
+    out["cs_v1"], out["cs_v2"], out["cs_pl"] = v1, v2, pl
+    out["cs_res"] = np.array([rtu.CheckSides(v1[i], v2[i], pl[i]) for i in range(200)])
+
+    # hemisphere source frame (GeneratePhoton's matrix) for a few emission directions
+    dirs = np.array([[0, 0, -1.0], [0, 0, 1.0], [1.0, 0, 0], [0.3, -0.4, 0.5], [0, 1.0, 0]])
+    out["frame_dirs"] = dirs
+    out["frame_tm"] = np.array([np.roll(rtu.MakeVectAxis(d), 2, axis=1) for d in dirs])
+    np.savez_compressed(os.path.join(HERE, "kat.npz"), **out)
+    print("kat:", sorted(out))
+
+
+def _tally_worker(args):
+    name, seed, n = args
+    ref = Reference()
+    try:
+        rt = ref.load_job(configs.make_job(name, n_photons=n))
+        ic = [0]
+        capped = [0]
+        steps = [0]
+
+        orig_reset = ref.mod["PhotonObject"].Photon.ResetPhoton
+        last = {"status": None}
+
+        def reset_hook(self_, plane):
+            if last["status"] == "InternalConverted":
+                ic[0] += 1
+            elif last["status"] is not None and last["status"] != "Dumped":
+                capped[0] += 1
+            orig_reset(self_, plane)
+            last["status"] = "pending"
+        ref.mod["PhotonObject"].Photon.ResetPhoton = reset_hook
+        orig_line = _DrawRecorder.DrawLine
+
+        def line(self_, a, b, c):
+            steps[0] += 1
+            last["status"] = rt.Photon.Status
+        _DrawRecorder.DrawLine = line
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            np.random.seed(seed)
+            rt.runSimulation()
+        dt = time.time() - t0
+        if last["status"] == "InternalConverted":
+            ic[0] += 1
+        elif last["status"] != "Dumped":
+            capped[0] += 1
+        t = collect_tallies(rt)
+        t.update(config=name, seed=seed, n=n, seconds=dt, ic=ic[0], capped=capped[0],
+                 steps=steps[0])
+        return t
+    finally:
+        ref.close()
+
+
+def gen_tallies(n=10000, seeds=range(1, 9), names=None, procs=8):
+    import multiprocessing as mp
+    names = names or ["C1", "C2", "C3", "C4", "C5", "C1_open"]
+    path = os.path.join(HERE, "ref_tallies.json")
+    results = json.load(open(path)) if os.path.exists(path) else []
+    done = {(r["config"], r["seed"], r["n"]) for r in results}
+    for name in names:
+        n_cfg = 1000 if name == "C1_open" else n
+        jobs = [(name, s, n_cfg) for s in seeds if (name, s, n_cfg) not in done]
+        if not jobs:
+            continue
+        with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
+            for r in pool.imap_unordered(_tally_worker, jobs):
+                results.append(r)
+                print(r["config"], r["seed"], "%.0fs" % r["seconds"],
+                      "edge", sum(r["counter"][2:6]), "ic", r["ic"], "capped", r["capped"],
+                      flush=True)
+        results.sort(key=lambda r: (r["config"], r["seed"]))
+        with open(path, "w") as fh:
+            json.dump(results, fh)
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("tallies",):
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+        names = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+        gen_tallies(n=n, names=names)
+        return
+    ref = Reference()
+    try:
+        if what in ("kat", "all"):
+            gen_kat(ref)
+        if what in ("materials", "all"):
+            gen_materials(ref)
+        if what in ("traces", "all"):
+            gen_traces(ref)
+    finally:
+        ref.close()
+
+
+if __name__ == "__main__":
+    main()
