@@ -1,0 +1,177 @@
+"""ctypes wrapper of liboracle.so -- TEST INFRASTRUCTURE, not product code.
+
+Only tests/, `__graft_entry__.smoke()` and the `cpu_baseline` leg of bench.py
+import this module.  It reuses the scene packing of the product's host layer
+(the description structs are the product's input format) and mirrors the
+method names of `raytracer_amd.scene.Scene` so that parity tests can run the
+same call on both sides.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import _abi
+from raytracer_amd import scene as _scene
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(HERE, "rtmc_oracle.c")
+    hdr = os.path.join(HERE, "..", "include", "rtmc.h")
+    if (force or not os.path.isfile(LIB_PATH)
+            or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", HERE, "-B", "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        f64p, u64p = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_scene_create.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(C.c_void_p)]
+        L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_scene_destroy.restype = None
+        L.orc_run.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                              C.POINTER(_abi.Tallies)]
+        L.orc_step_tape.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_abi.PhotonSoA), f64p, u64p,
+                                    C.c_uint32, C.c_int, f64p]
+        L.orc_op_intersect.argtypes = [C.c_void_p, C.c_uint32, f64p, f64p, f64p]
+        L.orc_material_info.argtypes = [C.c_void_p, C.c_int, f64p, f64p, f64p]
+        L.orc_op_interface.argtypes = [f64p, f64p, C.c_double, C.c_double, f64p, f64p, f64p, f64p]
+        L.orc_op_interface.restype = None
+        L.orc_find_closest.argtypes = [f64p, C.c_int64, C.c_double]
+        L.orc_find_closest.restype = C.c_int64
+        L.orc_check_sides.argtypes = [f64p, f64p, f64p, f64p]
+        L.orc_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_philox.restype = None
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise OracleError("oracle error %d: %s" % (rc, lib().orc_last_error().decode()))
+
+
+class OracleScene:
+    def __init__(self, optical_elements, photon, material_dict=None,
+                 max_iterations=_scene.REFERENCE_ITERATION_CAP):
+        self.packed = _scene.PackedScene(optical_elements, photon, material_dict, max_iterations)
+        self.n_elements = self.packed.n_elements
+        h = C.c_void_p()
+        _check(lib().orc_scene_create(C.byref(self.packed.desc), C.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def from_raytrace(cls, rt):
+        return cls(rt.OpticalElements, rt.Photon, rt.MaterialDict, rt.MaxIterations)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().orc_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, n_photons, seed=0, first_photon=0, tallies=None):
+        t, arrays = tallies if tallies is not None else _scene.new_tallies(self.n_elements)
+        _check(lib().orc_run(self.handle, seed, first_photon, n_photons, C.byref(t)))
+        return _scene.tallies_to_dict(t, arrays)
+
+    def run_threads(self, n_photons, seed=0, first_photon=0, threads=1):
+        """Split the id range over `threads` host threads (ctypes drops the GIL)."""
+        from concurrent.futures import ThreadPoolExecutor
+        from raytracer_amd.distributed import shard_range
+        blocks = [_scene.new_tallies(self.n_elements) for _ in range(threads)]
+
+        def work(i):
+            first, cnt = shard_range(n_photons, i, threads)
+            if cnt:
+                _check(lib().orc_run(self.handle, seed, first_photon + first, cnt,
+                                     C.byref(blocks[i][0])))
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, range(threads)))
+        total = _scene.tallies_to_dict(*blocks[0])
+        for b in blocks[1:]:
+            d = _scene.tallies_to_dict(*b)
+            for k, v in d.items():
+                total[k] = total[k] + v
+        return total
+
+    def step_tape(self, batch, tape, tape_off, n_steps, launch=False, trace=False):
+        n = batch["wavelength"].shape[0]
+        tape = np.ascontiguousarray(tape, dtype=np.float64)
+        tape_off = np.ascontiguousarray(tape_off, dtype=np.uint64)
+        tr = np.full((n, n_steps, _abi.TRACE_STRIDE), np.nan) if trace else None
+        s = _scene.batch_struct(batch)
+        _check(lib().orc_step_tape(self.handle, n, C.byref(s), _abi.f64_ptr(tape),
+                                   _abi.u64_ptr(tape_off), n_steps, int(bool(launch)),
+                                   _abi.f64_ptr(tr.reshape(-1)) if trace else None))
+        return tr
+
+    def intersect(self, loc, direction):
+        loc = np.ascontiguousarray(loc, dtype=np.float64).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((loc.shape[0], self.n_elements, 3))
+        _check(lib().orc_op_intersect(self.handle, loc.shape[0], _abi.f64_ptr(loc.reshape(-1)),
+                                      _abi.f64_ptr(direction.reshape(-1)),
+                                      _abi.f64_ptr(out.reshape(-1))))
+        return out
+
+    def material_info(self, mat_index):
+        m = self.packed.mat_array[mat_index]
+        pet = np.zeros(2)
+        cdf_a = np.zeros(max(1, m.em_A.len))
+        cdf_d = np.zeros(max(1, m.em_D.len))
+        _check(lib().orc_material_info(self.handle, mat_index, _abi.f64_ptr(pet),
+                                       _abi.f64_ptr(cdf_a), _abi.f64_ptr(cdf_d)))
+        return pet, cdf_a, cdf_d
+
+
+def op_interface(S, n, n1, n2, L, D, E):
+    """(tir, R, sgn), refracted(L,D,E), reflected(L,D,E) for one incidence."""
+    state = np.ascontiguousarray(np.concatenate([L, D, E]), dtype=np.float64)
+    res, refr, refl = np.zeros(3), np.zeros(9), np.zeros(9)
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    n = np.ascontiguousarray(n, dtype=np.float64)
+    lib().orc_op_interface(_abi.f64_ptr(S), _abi.f64_ptr(n), n1, n2, _abi.f64_ptr(state),
+                           _abi.f64_ptr(res), _abi.f64_ptr(refr), _abi.f64_ptr(refl))
+    return res, refr, refl
+
+
+def find_closest(A, t):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    return int(lib().orc_find_closest(_abi.f64_ptr(A), A.size, float(t)))
+
+
+def check_sides(v1, v2, S, n):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (v1, v2, S, n)]
+    return bool(lib().orc_check_sides(*[_abi.f64_ptr(a) for a in arrs]))
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox(c, k, o)
+    return list(o)

@@ -1,0 +1,942 @@
+/*
+ * rtmc_oracle.c -- TEST INFRASTRUCTURE, not product code.
+ *
+ * A scalar float64 restatement of the reference's photon loop
+ * (mohrezaeib/RayTracer, RayTrace.runSimulation and everything it calls), used
+ * only as the checker in tests/, in __graft_entry__.smoke() and as the
+ * `cpu_baseline` leg of bench.py.  Nothing in raytracer_amd/ loads it.
+ *
+ * It follows the reference statement by statement -- the arccos/arcsin
+ * Fresnel chain, the 1e-8 self-hit rule, the line-based reflection, the
+ * stale-element re-execution when nothing is hit -- and evaluates
+ * three-component dot products as fma(a2,b2, fma(a1,b1, a0*b0)), which is how
+ * numpy 2.2 + OpenBLAS round `np.dot` of 3-vectors on x86-64 (established
+ * empirically; numpy is an unpinned third-party dependency of the reference).
+ * With that, replaying a recorded variate tape of the reference reproduces its
+ * photon positions and directions bit for bit (tests/test_oracle_golden.py).
+ * Build with -ffp-contract=off.
+ *
+ * Two variate sources:
+ *   tape   -- the values the reference drew, in its order;
+ *   philox -- Philox4x32-10, key = seed, counter = (photon id, event, 0): the
+ *             same stream layout as the HIP kernels (csrc/rtmc_device.h), so a
+ *             GPU run and an oracle run of the same seed follow the same
+ *             photons.
+ *
+ * Reference file:line citations are given at each function.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rtmc.h"
+
+#define ORC_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* small vector helpers with the reference's rounding                  */
+/* ------------------------------------------------------------------ */
+static double dot3(const double *a, const double *b)
+{
+    return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]));
+}
+static double norm3(const double *a) { return sqrt(dot3(a, a)); }
+static void cross3(const double *a, const double *b, double *o)
+{
+    double x = a[1] * b[2] - a[2] * b[1];
+    double y = a[2] * b[0] - a[0] * b[2];
+    double z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static double sign1(double x) { return (x > 0) - (x < 0); } /* np.sign; NaN -> 0 here */
+
+/* ------------------------------------------------------------------ */
+/* scene                                                               */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int64_t len;
+    double *x; /* wavelengths */
+    double *y; /* values      */
+} tab_t;
+
+typedef struct {
+    rtmc_material m;
+    tab_t abs_A, abs_D, em_A, em_D;
+    double *cdf_A, *cdf_D; /* inverse-CDF tables of the emission draws */
+    double p[3], pA[3];
+    double cdf_p[3], cdf_pA[3];
+    int n_p;
+    double P_ET_DA, P_ET_AD;
+} omat_t;
+
+typedef struct orc_scene {
+    int n_el, n_mat, n_tab;
+    rtmc_element *el;
+    omat_t *mat;
+    tab_t *eqe;
+    rtmc_source src;
+    tab_t sun;
+    double *sun_cdf;
+    int max_iter;
+} orc_scene;
+
+static char g_err[512];
+ORC_EXPORT const char *orc_last_error(void) { return g_err; }
+
+static int tab_copy(tab_t *t, const rtmc_scene_desc *d, rtmc_table ref)
+{
+    t->len = ref.len;
+    t->x = t->y = NULL;
+    if (ref.len <= 0) return 0;
+    if (ref.offset < 0 || ref.offset + 2 * ref.len > d->table_data_len) return -1;
+    t->x = (double *)malloc(sizeof(double) * ref.len);
+    t->y = (double *)malloc(sizeof(double) * ref.len);
+    for (int64_t i = 0; i < ref.len; i++) {
+        t->x[i] = d->table_data[ref.offset + 2 * i];
+        t->y[i] = d->table_data[ref.offset + 2 * i + 1];
+    }
+    return 0;
+}
+static void tab_free(tab_t *t) { free(t->x); free(t->y); }
+
+/* RTUtils.py:15-22 FindClosestListElement */
+static int64_t find_closest(const double *A, int64_t n, double t)
+{
+    int64_t lo = 0, hi = n; /* searchsorted, side='left' */
+    while (lo < hi) {
+        int64_t mid = (lo + hi) / 2;
+        if (A[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    int64_t idx = lo;
+    if (idx < 1) idx = 1;
+    if (idx > n - 1) idx = n - 1;
+    double left = A[idx - 1], right = A[idx];
+    if (t - left < right - t) idx -= 1;
+    return idx;
+}
+
+/* RTUtils.py:152-158 RectifySpectrum followed by the cumulative sum that
+ * numpy.random.choice builds (cdf = p.cumsum(); cdf /= cdf[-1]) */
+static double *rectified_cdf(const double *x, const double *y, int64_t n, int times_lambda)
+{
+    double *w = (double *)malloc(sizeof(double) * n);
+    double s = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        double v = times_lambda ? y[i] * x[i] : y[i]; /* PhotonObject.py:44 */
+        if (i > 0) v *= (x[i] - x[i - 1]);
+        w[i] = v;
+        s += v;
+    }
+    double c = 0.0;
+    for (int64_t i = 0; i < n; i++) { c += w[i] / s; w[i] = c; }
+    double last = w[n - 1];
+    for (int64_t i = 0; i < n; i++) w[i] /= last;
+    return w;
+}
+
+/* searchsorted(cdf, u, side='right'): number of entries <= u */
+static int64_t cdf_pick(const double *cdf, int64_t n, double u)
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) / 2;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo < n ? lo : n - 1;
+}
+
+/* MonteCarloFRET.py:195-237 GenerateMolecules (photon independent) */
+static void generate_molecules(omat_t *M)
+{
+    const rtmc_material *m = &M->m;
+    const double pi = 3.141592653589793;
+    {
+        double R0 = ((9 * (2 / 3.0) * m->Q_D * log(10.0)) / (128 * pow(m->n, 4) * 6.022e23 * pow(pi, 5))) * m->ol_DA * 1e17;
+        R0 = pow(R0, 1 / 6.0);
+        R0 *= 1e-7;
+        double cA = m->conc_a * 6.022e17;
+        double c0 = 1.0 / ((4.0 / 3) * pi * (R0 * R0 * R0));
+        M->P_ET_DA = 1.0 - exp(-1.42 * cA / c0);
+    }
+    if (m->fix_dist) {
+        double invR6 = 1 / pow(m->fix_dist_R * 1e-9, 6);
+        double k = ((9 * (2 / 3.0) * m->Q_A * log(10.0)) / (128 * pow(m->n, 4) * 6.022e23 * pow(pi, 5) * m->tau_A)) * invR6 * 1e-54 * m->ol_AD * 1e17;
+        M->P_ET_AD = k / (1.0 / m->tau_A + k);
+    } else {
+        double R0 = ((9 * (2 / 3.0) * m->Q_A * log(10.0)) / (128 * pow(m->n, 4) * 6.022e23 * pow(pi, 5))) * m->ol_AD * 1e17;
+        R0 = pow(R0, 1 / 6.0);
+        R0 *= 1e-7;
+        double cD = m->conc_b * 6.022e17;
+        if (R0 > 0) {
+            double c0 = 1.0 / ((4.0 / 3) * pi * (R0 * R0 * R0));
+            M->P_ET_AD = 1.0 - exp(-1.42 * cD / c0);
+        } else
+            M->P_ET_AD = 0.0;
+    }
+}
+
+static void cdf3(const double *p, int n, double *cdf)
+{
+    double c = 0;
+    for (int i = 0; i < n; i++) { c += p[i]; cdf[i] = c; }
+    for (int i = 0; i < n; i++) cdf[i] /= c;
+}
+
+ORC_EXPORT void orc_scene_destroy(orc_scene *s)
+{
+    if (!s) return;
+    for (int i = 0; i < s->n_mat; i++) {
+        tab_free(&s->mat[i].abs_A); tab_free(&s->mat[i].abs_D);
+        tab_free(&s->mat[i].em_A); tab_free(&s->mat[i].em_D);
+        free(s->mat[i].cdf_A); free(s->mat[i].cdf_D);
+    }
+    for (int i = 0; i < s->n_tab; i++) tab_free(&s->eqe[i]);
+    tab_free(&s->sun);
+    free(s->sun_cdf);
+    free(s->el); free(s->mat); free(s->eqe);
+    free(s);
+}
+
+ORC_EXPORT int orc_scene_create(const rtmc_scene_desc *d, orc_scene **out)
+{
+    if (!d || !out || d->abi_version != RTMC_ABI_VERSION) {
+        snprintf(g_err, sizeof g_err, "bad description");
+        return RTMC_EINVAL;
+    }
+    orc_scene *s = (orc_scene *)calloc(1, sizeof *s);
+    s->n_el = d->n_elements; s->n_mat = d->n_materials; s->n_tab = d->n_tables;
+    s->el = (rtmc_element *)malloc(sizeof(rtmc_element) * (s->n_el > 0 ? s->n_el : 1));
+    memcpy(s->el, d->elements, sizeof(rtmc_element) * s->n_el);
+    s->mat = (omat_t *)calloc(s->n_mat > 0 ? s->n_mat : 1, sizeof(omat_t));
+    s->eqe = (tab_t *)calloc(s->n_tab > 0 ? s->n_tab : 1, sizeof(tab_t));
+    s->src = d->source;
+    s->max_iter = d->max_iterations;
+    for (int i = 0; i < s->n_el; i++) {
+        const rtmc_element *e = &s->el[i];
+        if (e->geometry != RTMC_GEOM_RECTANGLE ||
+            (e->type != RTMC_TYPE_MIRROR && e->type != RTMC_TYPE_INTERFACE && e->type != RTMC_TYPE_DUMP)) {
+            snprintf(g_err, sizeof g_err, "element %d: geometry %d / type %d not restated yet", i, e->geometry, e->type);
+            orc_scene_destroy(s);
+            return RTMC_EUNSUPPORTED;
+        }
+    }
+    for (int i = 0; i < s->n_mat; i++) {
+        omat_t *M = &s->mat[i];
+        M->m = d->materials[i];
+        if (!M->m.is_absorber) continue;
+        if (M->m.is_aligned) {
+            snprintf(g_err, sizeof g_err, "material %d: aligned dyes not restated yet", i);
+            orc_scene_destroy(s);
+            return RTMC_EUNSUPPORTED;
+        }
+        if (tab_copy(&M->abs_A, d, M->m.abs_A) || tab_copy(&M->abs_D, d, M->m.abs_D) ||
+            tab_copy(&M->em_A, d, M->m.em_A) || tab_copy(&M->em_D, d, M->m.em_D)) {
+            snprintf(g_err, sizeof g_err, "material %d: table out of range", i);
+            orc_scene_destroy(s);
+            return RTMC_EINVAL;
+        }
+        M->cdf_A = rectified_cdf(M->em_A.x, M->em_A.y, M->em_A.len, 0);
+        M->cdf_D = rectified_cdf(M->em_D.x, M->em_D.y, M->em_D.len, 0);
+        /* MonteCarloFRET.py:64-82 */
+        if (M->m.conc_a > 0) {
+            generate_molecules(M);
+            M->p[0] = (1 - M->P_ET_DA) * M->m.Q_D;
+            M->p[1] = (1 - M->P_ET_DA) * (1 - M->m.Q_D);
+            M->p[2] = M->P_ET_DA;
+            M->pA[0] = (1 - M->P_ET_AD) * M->m.Q_A;
+            M->pA[1] = (1 - M->P_ET_AD) * (1 - M->m.Q_A);
+            M->pA[2] = M->P_ET_AD;
+            M->n_p = 3;
+            cdf3(M->pA, 3, M->cdf_pA);
+        } else {
+            M->p[0] = M->m.Q_D; M->p[1] = 1 - M->m.Q_D;
+            M->n_p = 2;
+        }
+        cdf3(M->p, M->n_p, M->cdf_p);
+    }
+    for (int i = 0; i < s->n_tab; i++)
+        if (tab_copy(&s->eqe[i], d, d->tables[i])) { orc_scene_destroy(s); return RTMC_EINVAL; }
+    if (s->src.wavelength_mode == 1) {
+        if (tab_copy(&s->sun, d, s->src.spectrum) || s->sun.len < 1) { orc_scene_destroy(s); return RTMC_EINVAL; }
+        s->sun_cdf = rectified_cdf(s->sun.x, s->sun.y, s->sun.len, 1);
+    }
+    *out = s;
+    return RTMC_OK;
+}
+
+/* exported for tests: transfer probabilities and emission CDFs as restated */
+ORC_EXPORT int orc_material_info(const orc_scene *s, int mat, double *pet2, double *cdfA, double *cdfD)
+{
+    if (mat < 0 || mat >= s->n_mat) return RTMC_EINVAL;
+    const omat_t *M = &s->mat[mat];
+    pet2[0] = M->P_ET_DA; pet2[1] = M->P_ET_AD;
+    if (cdfA && M->cdf_A) memcpy(cdfA, M->cdf_A, sizeof(double) * M->em_A.len);
+    if (cdfD && M->cdf_D) memcpy(cdfD, M->cdf_D, sizeof(double) * M->em_D.len);
+    return RTMC_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* variates                                                            */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int tape_mode;
+    const double *tape;
+    uint64_t pos, end;
+    int overrun;
+    uint32_t key[2], pid[2], event;
+    uint32_t w[4];
+} rng_t;
+
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+ORC_EXPORT void orc_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
+
+/* start a new draw event: in philox mode one fresh block of four words */
+static void rng_event(rng_t *g)
+{
+    if (g->tape_mode) return;
+    uint32_t ctr[4] = {g->pid[0], g->pid[1], g->event, 0};
+    philox4x32_10(ctr, g->key, g->w);
+    g->event++;
+}
+static double tape_next(rng_t *g)
+{
+    if (g->pos >= g->end) { g->overrun = 1; return 0.5; }
+    return g->tape[g->pos++];
+}
+static double u24(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
+static double rng_uniform(rng_t *g, int slot) { return g->tape_mode ? tape_next(g) : u24(g->w[slot]); }
+/* unit-scale exponential: numpy legacy = -log(1 - U) */
+static double rng_exponential(rng_t *g, int slot) { return g->tape_mode ? tape_next(g) : -log(1.0 - u24(g->w[slot])); }
+/* three standard normals; philox: Box-Muller on (w0,w1) and (w2,w3) */
+static void rng_normal3(rng_t *g, double *o)
+{
+    if (g->tape_mode) { o[0] = tape_next(g); o[1] = tape_next(g); o[2] = tape_next(g); return; }
+    const double two_pi = 6.283185307179586;
+    double r0 = sqrt(-2.0 * log(((double)(g->w[0] >> 8) + 1.0) * (1.0 / 16777216.0)));
+    double t0 = two_pi * u24(g->w[1]);
+    double r1 = sqrt(-2.0 * log(((double)(g->w[2] >> 8) + 1.0) * (1.0 / 16777216.0)));
+    double t1 = two_pi * u24(g->w[3]);
+    o[0] = r0 * cos(t0); o[1] = r0 * sin(t0); o[2] = r1 * cos(t1);
+}
+
+/* ------------------------------------------------------------------ */
+/* photon                                                              */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    double L[3], D[3], E[3];
+    double wl, wl0, dist_left;
+    int mat, status, was_element, reflected;
+    double sgn;
+    double op_S[3], op_n[3];       /* Photon.OperationPlane              */
+    double old_point[3];           /* Photon.OldPoint                    */
+    double old_dir[3];
+    double point_cy[3];
+    int been_absorbed;
+    /* RayTrace loop variables */
+    double drv_old_point[3];
+    int first_el, old_el;
+    double smallest;
+    int iter;
+    int stale;        /* last iteration found no element */
+    int absorbed_now; /* last iteration absorbed the photon */
+} ph_t;
+
+/* PhotonObject.py:107-114 UpdatePolarizationRandom */
+static void polarization_random(ph_t *p, rng_t *g, const double *dir)
+{
+    double v[3];
+    rng_event(g);
+    rng_normal3(g, v);
+    double n = norm3(v);
+    v[0] /= n; v[1] /= n; v[2] /= n;
+    cross3(dir, v, p->E);
+    n = norm3(p->E);
+    p->E[0] /= n; p->E[1] /= n; p->E[2] /= n;
+}
+
+/* RTUtils.py:102-108 GenerateDirectionSine */
+static void direction_isotropic(rng_t *g, double *d)
+{
+    rng_event(g);
+    rng_normal3(g, d);
+    double n = norm3(d);
+    d[0] /= n; d[1] /= n; d[2] /= n;
+}
+
+/* PhotonObject.py:283-305 LamBeerDistance (non-aligned) */
+static void lambeer_distance(const orc_scene *s, ph_t *p, rng_t *g, int slot)
+{
+    const omat_t *M = &s->mat[p->mat];
+    if (M->m.is_absorber) {
+        double ea = M->abs_A.y[find_closest(M->abs_A.x, M->abs_A.len, p->wl)];
+        double ed = M->abs_D.y[find_closest(M->abs_D.x, M->abs_D.len, p->wl)];
+        double b_a = M->m.conc_a * 1e-3 * M->m.emax_A * log(10.0) * fmax(1e-99, ea);
+        double b_d = M->m.conc_b * 1e-3 * M->m.emax_D * log(10.0) * fmax(1e-99, ed);
+        double scale = 1.0 / (b_a + b_d);
+        p->dist_left = (1 / s->src.scale_factor) * (scale * rng_exponential(g, slot));
+    } else
+        p->dist_left = 0.0;
+}
+
+/* PhotonObject.py:49-97 ResetPhoton / GeneratePhoton */
+static void launch_photon(const orc_scene *s, ph_t *p, rng_t *g)
+{
+    const rtmc_source *src = &s->src;
+    p->was_element = 0;
+    memcpy(p->L, src->location, sizeof p->L);
+    if (src->direction_mode == 1) {
+        double d[3];
+        direction_isotropic(g, d);
+        d[2] = fabs(d[2]);
+        for (int j = 0; j < 3; j++) /* row vector times matrix */
+            p->D[j] = fma(d[2], src->frame[6 + j], fma(d[1], src->frame[3 + j], d[0] * src->frame[j]));
+    } else
+        memcpy(p->D, src->direction, sizeof p->D);
+    double n = norm3(p->D);
+    p->D[0] /= n; p->D[1] /= n; p->D[2] /= n;
+    if (src->wavelength_mode == 1) {
+        rng_event(g);
+        p->wl = s->sun.x[cdf_pick(s->sun_cdf, s->sun.len, rng_uniform(g, 0))];
+    } else
+        p->wl = src->wavelength;
+    p->mat = src->start_material;
+    polarization_random(p, g, p->D);
+    p->wl0 = p->wl;
+    p->reflected = 0;
+    if (s->n_el > 0) {
+        memcpy(p->op_S, s->el[0].support, sizeof p->op_S);
+        memcpy(p->op_n, s->el[0].normal, sizeof p->op_n);
+    }
+    /* state the reference carries over from the previous photon and that a
+       batched engine cannot: see the header of this file */
+    p->dist_left = 0.0;
+    p->status = RTMC_ST_START;
+    p->first_el = p->old_el = -1;
+    p->been_absorbed = 0;
+    p->iter = 0;
+    p->sgn = 1;
+    memcpy(p->drv_old_point, p->L, sizeof p->L);
+    memcpy(p->old_point, p->L, sizeof p->L);
+    memset(p->point_cy, 0, sizeof p->point_cy);
+    p->smallest = INFINITY;
+}
+
+/* Geometries.py:32-52 Rectangle.FindIntersections; returns 0 for [nan]*3 */
+static int rect_intersect(const rtmc_element *e, const double *L, const double *D, double *B)
+{
+    double dn = dot3(D, e->normal);
+    if (dn != 0) {
+        double sl[3] = {e->support[0] - L[0], e->support[1] - L[1], e->support[2] - L[2]};
+        double t = dot3(sl, e->normal) / dn;
+        double d[3];
+        for (int j = 0; j < 3; j++) { B[j] = t * D[j] + L[j]; d[j] = B[j] - e->support[j]; }
+        double t1 = dot3(e->e1, d), t2 = dot3(e->e2, d);
+        if (e->half1 < fabs(t1) || e->half2 < fabs(t2)) return 0;
+        /* np.all(point != [nan]*3) is also False for a point that contains no NaN... it is
+           True for every array; a NaN coordinate compares unequal as well, so any array passes */
+        return 1;
+    }
+    return 0;
+}
+
+/* RTUtils.py:6-11 CheckSides */
+static int check_sides(const double *v1, const double *v2, const double *S, const double *n)
+{
+    double off = (S[0] * n[0] + S[1] * n[1]) + S[2] * n[2];
+    double a = ((n[0] * v1[0] + n[1] * v1[1]) + n[2] * v1[2]) - off;
+    double b = ((n[0] * v2[0] + n[1] * v2[1]) + n[2] * v2[2]) - off;
+    return sign1(a) == sign1(b);
+}
+
+/* Elements.py:26-28,113-114,131-132 IsValidNextPoint of the previous element */
+static int valid_next(const orc_scene *s, const ph_t *p, const double *pt)
+{
+    int same = check_sides(p->drv_old_point, pt, p->op_S, p->op_n);
+    int type = s->el[p->old_el].type;
+    if (type == RTMC_TYPE_MIRROR) return same == 1;
+    if (type == RTMC_TYPE_INTERFACE) return same == p->reflected;
+    if (type == RTMC_TYPE_LENS) return same == 0;
+    return 0;
+}
+
+/* RayTrace.py:120-154 CheckElementsForCrossingPoint */
+static void find_crossing(const orc_scene *s, ph_t *p)
+{
+    p->smallest = INFINITY;
+    p->point_cy[0] = p->point_cy[1] = p->point_cy[2] = 0;
+    for (int i = 0; i < s->n_el; i++) {
+        double pt[3];
+        if (!rect_intersect(&s->el[i], p->L, p->D, pt)) continue;
+        double df[3] = {p->L[0] - pt[0], p->L[1] - pt[1], p->L[2] - pt[2]};
+        double dist = norm3(df);
+        if (dist < p->smallest && dist > 1e-8) {
+            int take;
+            if (p->was_element)
+                take = p->old_el >= 0 ? valid_next(s, p, pt) : 0;
+            else {
+                int k = p->D[0] != 0 ? 0 : (p->D[1] != 0 ? 1 : 2);
+                take = (pt[k] - p->L[k]) / p->D[k] > 0;
+            }
+            if (take) {
+                p->smallest = dist;
+                p->first_el = i;
+                memcpy(p->point_cy, pt, sizeof pt);
+            }
+        }
+    }
+    p->old_el = p->first_el;
+}
+
+/* MonteCarloFRET.py:258-279 EmitWavelength */
+static double emit_wavelength(const omat_t *M, int donor, double u)
+{
+    if (donor) return M->em_D.x[cdf_pick(M->cdf_D, M->em_D.len, u)];
+    return M->em_A.x[cdf_pick(M->cdf_A, M->em_A.len, u)];
+}
+
+/* MonteCarloFRET.py:63-193 RunSimulation (non-aligned acceptor).  `have_block`:
+ * the caller has already opened the draw event (its word 0 was the
+ * donor/acceptor coin). */
+static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int have_block)
+{
+    const omat_t *M = &s->mat[p->mat];
+    for (;;) {
+        double u_lambda = 0;
+        if (!have_block) rng_event(g);
+        if (!g->tape_mode) u_lambda = u24(g->w[3]); /* saved before later events replace the block */
+        have_block = 0;
+        /* MonteCarloFRET.py:90 -- drawn even when the acceptor was excited */
+        int pathway = (int)cdf_pick(M->cdf_p, M->n_p, rng_uniform(g, 1));
+        if (pathway == 0 && in_donor) {
+            /* MonteCarloFRET.py:92-105: direction, wavelength, polarisation */
+            direction_isotropic(g, p->D);
+            if (g->tape_mode) u_lambda = tape_next(g);
+            p->wl = emit_wavelength(M, 1, u_lambda);
+            p->status = RTMC_ST_REEMITTED_DONOR;
+            polarization_random(p, g, p->D);
+            return;
+        }
+        if (pathway == 1 && in_donor) { /* :106-109 */
+            p->status = RTMC_ST_INTERNAL_CONVERTED;
+            return;
+        }
+        /* :110-119 acceptor excited (directly or by transfer) */
+        int pa = (int)cdf_pick(M->cdf_pA, 3, rng_uniform(g, 2));
+        if (pa == 0) {
+            /* :170-175 direction, polarisation, wavelength */
+            direction_isotropic(g, p->D);
+            polarization_random(p, g, p->D);
+            if (g->tape_mode) u_lambda = tape_next(g);
+            p->wl = emit_wavelength(M, 0, u_lambda);
+            p->status = RTMC_ST_REEMITTED_ACCEPTOR;
+            return;
+        }
+        if (pa == 1) { /* :182-185 */
+            p->status = RTMC_ST_INTERNAL_CONVERTED;
+            return;
+        }
+        in_donor = 1; /* :187-190 back transfer, start over in the donor */
+    }
+}
+
+/* PhotonObject.py:206-264 CheckForAbsorption */
+static void check_absorption(const orc_scene *s, ph_t *p, rng_t *g, const double *old_point, double smallest)
+{
+    const omat_t *M = &s->mat[p->mat];
+    memcpy(p->old_point, old_point, sizeof p->old_point);
+    if (M->m.is_absorber) {
+        if (p->dist_left > smallest) {
+            p->dist_left -= smallest;
+            p->status = RTMC_ST_START;
+        } else {
+            p->been_absorbed = 1;
+            p->was_element = 0;
+            memcpy(p->old_point, p->L, sizeof p->L);
+            p->status = RTMC_ST_ABSORBED;
+            double r[3] = {p->point_cy[0] - p->L[0], p->point_cy[1] - p->L[1], p->point_cy[2] - p->L[2]};
+            double n = norm3(r);
+            for (int j = 0; j < 3; j++) { r[j] /= n; p->L[j] = r[j] * p->dist_left + p->L[j]; }
+            double ed = M->abs_D.y[find_closest(M->abs_D.x, M->abs_D.len, p->wl)];
+            double ea = M->abs_A.y[find_closest(M->abs_A.x, M->abs_A.len, p->wl)];
+            double b_d = M->m.conc_b * 1e-3 * log(10.0) * M->m.emax_D * fmax(1e-99, ed);
+            double b_a = M->m.conc_a * 1e-3 * log(10.0) * M->m.emax_A * fmax(1e-99, ea);
+            rng_event(g);
+            int in_donor = rng_uniform(g, 0) < b_d / (b_d + b_a);
+            fret_event(s, p, g, in_donor, 1);
+            p->absorbed_now = 1;
+            /* PhotonObject.py:250/258: a new free path is drawn whatever happened */
+            if (g->tape_mode || p->status != RTMC_ST_INTERNAL_CONVERTED) {
+                rng_event(g);
+                lambeer_distance(s, p, g, 0);
+            }
+        }
+    } else {
+        p->status = RTMC_ST_START;
+        p->was_element = 1;
+    }
+}
+
+/* PhotonObject.py:135-139 PrepareExecution */
+static void prepare_execution(ph_t *p)
+{
+    p->sgn = sign1(-dot3(p->D, p->op_n));
+    memcpy(p->old_point, p->L, sizeof p->L);
+    memcpy(p->old_dir, p->D, sizeof p->D);
+}
+
+/* PhotonObject.py:145-154 ReflectOnPlane */
+static void reflect_on_plane(ph_t *p)
+{
+    double sl[3] = {p->op_S[0] - p->L[0], p->op_S[1] - p->L[1], p->op_S[2] - p->L[2]};
+    double t = dot3(sl, p->op_n) / dot3(p->D, p->op_n);
+    for (int j = 0; j < 3; j++) p->L[j] = t * p->D[j] + p->L[j];
+    double c = 2 * dot3(p->op_n, p->D);
+    for (int j = 0; j < 3; j++) p->D[j] = c * p->op_n[j] - p->D[j];
+}
+
+/* PhotonObject.py:195-203 RefractOnPlane */
+static void refract_on_plane(ph_t *p, double n1, double n2)
+{
+    double sl[3] = {p->op_S[0] - p->L[0], p->op_S[1] - p->L[1], p->op_S[2] - p->L[2]};
+    double t = dot3(sl, p->op_n) / dot3(p->D, p->op_n);
+    for (int j = 0; j < 3; j++) p->L[j] = t * p->D[j] + p->L[j];
+    double r = n1 / n2;
+    double c = -dot3(p->D, p->op_n);
+    double k = r * c - p->sgn * sqrt(1 - (r * r) * (1 - c * c));
+    for (int j = 0; j < 3; j++) p->D[j] = r * p->D[j] + k * p->op_n[j];
+}
+
+/* RTUtils.py:110-123 RotationMatrix applied to a vector */
+static void rotate(const double *axis_in, double theta, double *v)
+{
+    double nn = sqrt(dot3(axis_in, axis_in));
+    double ax[3] = {axis_in[0] / nn, axis_in[1] / nn, axis_in[2] / nn};
+    double a = cos(theta / 2.0);
+    double sn = sin(theta / 2.0);
+    double b = -ax[0] * sn, c = -ax[1] * sn, d = -ax[2] * sn;
+    double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    double bc = b * c, ad = a * d, ac = a * c, ab = a * b, bd = b * d, cd = c * d;
+    double m[3][3] = {{aa + bb - cc - dd, 2 * (bc + ad), 2 * (bd - ac)},
+                      {2 * (bc - ad), aa + cc - bb - dd, 2 * (cd + ab)},
+                      {2 * (bd + ac), 2 * (cd - ab), aa + dd - bb - cc}};
+    double o[3];
+    for (int i = 0; i < 3; i++) o[i] = dot3(m[i], v);
+    v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+}
+
+/* PhotonObject.py:117-129,141-143 PostProcessExecution / UpdatePolarization */
+static void post_process(ph_t *p)
+{
+    double cp[3];
+    cross3(p->D, p->old_dir, cp);
+    if (norm3(cp) != 0) {
+        double acs = dot3(p->D, p->old_dir) / (norm3(p->D) * norm3(p->old_dir));
+        if (acs <= 1.0 && acs >= -1.0) {
+            rotate(cp, -acos(acs), p->E);
+            double n = norm3(p->E);
+            p->E[0] /= n; p->E[1] /= n; p->E[2] /= n;
+        }
+    }
+    p->was_element = 1;
+}
+
+/* Elements.py:75-81 IsTotalReflect */
+static int is_total_reflect(const ph_t *p, double n1, double n2)
+{
+    double mn[3] = {-p->sgn * p->op_n[0], -p->sgn * p->op_n[1], -p->sgn * p->op_n[2]};
+    double thetai = acos(dot3(p->D, mn) / (norm3(p->D) * norm3(p->op_n)));
+    return n1 > n2 && fabs(thetai) > asin(n2 / n1);
+}
+
+/* Elements.py:84-109 Reflectance */
+static double reflectance(ph_t *p, double n1, double n2)
+{
+    double sn[3] = {p->sgn * p->op_n[0], p->sgn * p->op_n[1], p->sgn * p->op_n[2]};
+    double thetai = acos(-dot3(p->D, sn));
+    double thetat = asin((n1 / n2) * sin(thetai));
+    double ci = cos(thetai), ct = cos(thetat);
+    double rp = (n1 * ci - n2 * ct) / (n1 * ci + n2 * ct);
+    double rl = (n2 * ci - n1 * ct) / (n2 * ci + n1 * ct);
+    double R_perp = rp * rp, R_par = rl * rl;
+    double en = norm3(p->E);
+    p->E[0] /= en; p->E[1] /= en; p->E[2] /= en; /* the reference normalises E in place */
+    double nee[3];
+    cross3(p->D, sn, nee);
+    double nrm = norm3(nee);
+    if (nrm != 0) {
+        nee[0] /= nrm; nee[1] /= nrm; nee[2] /= nrm;
+        double dp = dot3(p->E, nee);
+        double par[3] = {p->E[0] - dp * nee[0], p->E[1] - dp * nee[1], p->E[2] - dp * nee[2]};
+        double parproj = norm3(par);
+        double sproj = fabs(dp);
+        return (parproj * parproj) * R_par + (sproj * sproj) * R_perp;
+    }
+    double q = (n1 - n2) / (n1 + n2);
+    return q * q;
+}
+
+/* Elements.py:41-73 Interface.ExecuteOperation */
+static void interface_op(const orc_scene *s, ph_t *p, rng_t *g, int el, rtmc_tallies *t)
+{
+    const rtmc_element *e = &s->el[el];
+    prepare_execution(p);
+    int other = (s->mat[p->mat].m.name_id == s->mat[e->material1].m.name_id) ? e->material2 : e->material1;
+    double n1 = s->mat[p->mat].m.n, n2 = s->mat[other].m.n;
+    rng_event(g);
+    if (is_total_reflect(p, n1, n2)) {
+        reflect_on_plane(p);
+        p->reflected = 1;
+        if (t) t->bounce[el]++;
+    } else {
+        double R = reflectance(p, n1, n2);
+        if (rng_uniform(g, 0) > R) {
+            refract_on_plane(p, n1, n2);
+            p->mat = other;
+            p->reflected = 0;
+            lambeer_distance(s, p, g, 1);
+        } else {
+            reflect_on_plane(p);
+            p->reflected = 1;
+            if (t) t->bounce[el]++;
+        }
+    }
+    post_process(p);
+}
+
+/* Elements.py:18-23 Mirror.ExecuteOperation */
+static void mirror_op(ph_t *p, int el, rtmc_tallies *t)
+{
+    prepare_execution(p);
+    reflect_on_plane(p);
+    if (t) t->bounce[el]++;
+    post_process(p);
+}
+
+/* Elements.py:152-169 Dump.ExecuteOperation */
+static void dump_op(const orc_scene *s, ph_t *p, rng_t *g, int el, rtmc_tallies *t)
+{
+    const rtmc_element *e = &s->el[el];
+    prepare_execution(p);
+    p->status = RTMC_ST_DUMPED;
+    int counted = 1;
+    if (e->eqe_table >= 0) {
+        const tab_t *q = &s->eqe[e->eqe_table];
+        rng_event(g);
+        counted = q->y[find_closest(q->x, q->len, p->wl)] > rng_uniform(g, 0);
+    }
+    if (t) {
+        t->counter[el]++;
+        double ratio = 1 * p->wl0 / p->wl;
+        t->energy_fx[el] += (uint64_t)llrint(ratio * RTMC_ENERGY_FX_SCALE);
+        /* IncidentSpectrum bins are the integers 200..3999 */
+        double lo = RTMC_SPECTRUM_FIRST_NM;
+        int64_t idx;
+        { /* FindClosestListElement on arange(200, 4000) */
+            double tw = p->wl;
+            int64_t ss = (int64_t)ceil(tw - lo); /* searchsorted left: first k with lo+k >= t */
+            if (ss < 0) ss = 0;
+            if (ss > RTMC_SPECTRUM_BINS) ss = RTMC_SPECTRUM_BINS;
+            idx = ss;
+            if (idx < 1) idx = 1;
+            if (idx > RTMC_SPECTRUM_BINS - 1) idx = RTMC_SPECTRUM_BINS - 1;
+            double left = lo + (double)(idx - 1), right = lo + (double)idx;
+            if (tw - left < right - tw) idx -= 1;
+        }
+        t->spectrum[(int64_t)el * RTMC_SPECTRUM_BINS + idx]++;
+        if (counted) t->spectral[el]++;
+    }
+    memcpy(p->L, p->point_cy, sizeof p->L);
+    post_process(p);
+}
+
+/* one iteration of the loop body, RayTrace.py:178-195; returns 0 when the photon stops */
+static int loop_iteration(const orc_scene *s, ph_t *p, rng_t *g, rtmc_tallies *t)
+{
+    find_crossing(s, p);
+    p->stale = !isfinite(p->smallest);
+    p->absorbed_now = 0;
+    if (p->old_el < 0) { /* the reference would fail with AttributeError (no FirstEl yet) */
+        p->status = RTMC_ST_LOST;
+        p->iter++;
+        return 0;
+    }
+    check_absorption(s, p, g, p->drv_old_point, p->smallest);
+    memcpy(p->drv_old_point, p->old_point, sizeof p->old_point);
+    if (p->status == RTMC_ST_START) {
+        const rtmc_element *e = &s->el[p->old_el];
+        memcpy(p->op_S, e->support, sizeof p->op_S);
+        memcpy(p->op_n, e->normal, sizeof p->op_n);
+        if (e->type == RTMC_TYPE_INTERFACE) interface_op(s, p, g, p->old_el, t);
+        else if (e->type == RTMC_TYPE_MIRROR) mirror_op(p, p->old_el, t);
+        else if (e->type == RTMC_TYPE_DUMP) dump_op(s, p, g, p->old_el, t);
+        memcpy(p->drv_old_point, p->old_point, sizeof p->old_point);
+    }
+    int stop = p->status == RTMC_ST_INTERNAL_CONVERTED || p->status == RTMC_ST_DUMPED ||
+               p->iter >= s->max_iter - 1;
+    p->iter++;
+    return !stop;
+}
+
+static void count_fate(const ph_t *p, rtmc_tallies *t)
+{
+    t->n_photons++;
+    t->n_steps += (uint64_t)p->iter;
+    if (p->been_absorbed) t->n_absorbed_once++;
+    if (p->status == RTMC_ST_INTERNAL_CONVERTED) t->n_internal_converted++;
+    else if (p->status == RTMC_ST_DUMPED) t->n_dumped++;
+    else if (p->status == RTMC_ST_LOST) t->n_lost++;
+    else t->n_capped++;
+}
+
+/* RayTrace.py:166-201 for photon ids [first, first+n) */
+ORC_EXPORT int orc_run(const orc_scene *s, uint64_t seed, uint64_t first, uint64_t n, rtmc_tallies *out)
+{
+    if (!s || !out || out->n_elements != s->n_el) {
+        snprintf(g_err, sizeof g_err, "bad arguments");
+        return RTMC_EINVAL;
+    }
+    for (uint64_t k = 0; k < n; k++) {
+        uint64_t id = first + k;
+        rng_t g;
+        memset(&g, 0, sizeof g);
+        g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32);
+        g.pid[0] = (uint32_t)id; g.pid[1] = (uint32_t)(id >> 32);
+        ph_t p;
+        memset(&p, 0, sizeof p);
+        launch_photon(s, &p, &g);
+        for (;;) {
+            int go = loop_iteration(s, &p, &g, out);
+            if (p.stale) out->n_stale_steps++;
+            if (p.absorbed_now) out->n_absorptions++;
+            if (!go) break;
+        }
+        count_fate(&p, out);
+    }
+    return RTMC_OK;
+}
+
+static void soa_load(const rtmc_photon_soa *b, uint32_t k, ph_t *p, const orc_scene *s)
+{
+    memset(p, 0, sizeof *p);
+    for (int j = 0; j < 3; j++) {
+        p->L[j] = b->loc[j][k]; p->D[j] = b->dir[j][k]; p->E[j] = b->efield[j][k];
+        p->drv_old_point[j] = b->old_point[j][k];
+        p->old_point[j] = b->old_point[j][k];
+    }
+    p->wl = b->wavelength[k]; p->wl0 = b->start_wavelength[k]; p->dist_left = b->dist_left[k];
+    p->mat = b->material[k]; p->status = b->status[k];
+    p->first_el = p->old_el = b->last_element[k];
+    p->was_element = b->was_element[k]; p->reflected = b->reflected[k];
+    p->iter = b->iterations[k];
+    p->smallest = INFINITY;
+    if (p->old_el >= 0 && p->old_el < s->n_el) {
+        memcpy(p->op_S, s->el[p->old_el].support, sizeof p->op_S);
+        memcpy(p->op_n, s->el[p->old_el].normal, sizeof p->op_n);
+    }
+}
+static void soa_store(rtmc_photon_soa *b, uint32_t k, const ph_t *p, const rng_t *g, uint64_t tape_base)
+{
+    for (int j = 0; j < 3; j++) {
+        b->loc[j][k] = p->L[j]; b->dir[j][k] = p->D[j]; b->efield[j][k] = p->E[j];
+        b->old_point[j][k] = p->drv_old_point[j];
+    }
+    b->wavelength[k] = p->wl; b->start_wavelength[k] = p->wl0; b->dist_left[k] = p->dist_left;
+    b->hit_distance[k] = p->smallest;
+    b->material[k] = p->mat; b->status[k] = p->status; b->last_element[k] = p->old_el;
+    b->was_element[k] = p->was_element; b->reflected[k] = p->reflected; b->iterations[k] = p->iter;
+    b->tape_pos[k] = (int32_t)(g->pos - tape_base);
+}
+
+/* same contract as rtmc_step_tape (include/rtmc.h) */
+ORC_EXPORT int orc_step_tape(const orc_scene *s, uint32_t n, rtmc_photon_soa *b, const double *tape,
+                             const uint64_t *tape_off, uint32_t n_steps, int launch, double *trace)
+{
+    int overrun = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        rng_t g;
+        memset(&g, 0, sizeof g);
+        g.tape_mode = 1; g.tape = tape;
+        g.pos = tape_off[k] + (launch ? 0 : (uint64_t)b->tape_pos[k]);
+        g.end = tape_off[k + 1];
+        ph_t p;
+        if (launch) { memset(&p, 0, sizeof p); launch_photon(s, &p, &g); }
+        else soa_load(b, k, &p, s);
+        int alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
+                      p.status == RTMC_ST_LOST || p.iter >= s->max_iter);
+        for (uint32_t it = 0; it < n_steps && alive; it++) {
+            alive = loop_iteration(s, &p, &g, NULL);
+            if (trace) {
+                double *r = trace + ((uint64_t)k * n_steps + it) * RTMC_TRACE_STRIDE;
+                for (int j = 0; j < 3; j++) { r[j] = p.L[j]; r[3 + j] = p.D[j]; r[6 + j] = p.E[j]; }
+                r[9] = p.wl; r[10] = p.dist_left; r[11] = p.status; r[12] = p.mat;
+                r[13] = p.old_el; r[14] = p.smallest; r[15] = (double)(g.pos - tape_off[k]);
+            }
+        }
+        overrun |= g.overrun;
+        soa_store(b, k, &p, &g, tape_off[k]);
+    }
+    if (overrun) {
+        snprintf(g_err, sizeof g_err, "variate tape exhausted");
+        return RTMC_EINVAL;
+    }
+    return RTMC_OK;
+}
+
+/* same contract as rtmc_op_intersect */
+ORC_EXPORT int orc_op_intersect(const orc_scene *s, uint32_t n, const double *loc, const double *dir, double *out)
+{
+    for (uint32_t k = 0; k < n; k++)
+        for (int i = 0; i < s->n_el; i++) {
+            double *o = out + ((uint64_t)k * s->n_el + i) * 3;
+            if (!rect_intersect(&s->el[i], loc + 3 * k, dir + 3 * k, o)) o[0] = o[1] = o[2] = NAN;
+        }
+    return RTMC_OK;
+}
+
+/* single operations on caller-supplied state, for the known-answer vectors:
+ * in/out rows of 9 doubles (L, D, E); plane = S[3], n[3]; returns TIR flag,
+ * reflectance and sgn in res[3] */
+ORC_EXPORT void orc_op_interface(const double *S, const double *n, double n1, double n2, const double *state,
+                                 double *res, double *refracted, double *reflected)
+{
+    ph_t p;
+    memset(&p, 0, sizeof p);
+    memcpy(p.L, state, 24); memcpy(p.D, state + 3, 24); memcpy(p.E, state + 6, 24);
+    memcpy(p.op_S, S, 24); memcpy(p.op_n, n, 24);
+    prepare_execution(&p);
+    res[0] = is_total_reflect(&p, n1, n2);
+    ph_t q = p;
+    res[1] = reflectance(&q, n1, n2);
+    res[2] = p.sgn;
+    q = p;
+    refract_on_plane(&q, n1, n2);
+    post_process(&q);
+    memcpy(refracted, q.L, 24); memcpy(refracted + 3, q.D, 24); memcpy(refracted + 6, q.E, 24);
+    q = p;
+    reflect_on_plane(&q);
+    post_process(&q);
+    memcpy(reflected, q.L, 24); memcpy(reflected + 3, q.D, 24); memcpy(reflected + 6, q.E, 24);
+}
+
+ORC_EXPORT int64_t orc_find_closest(const double *A, int64_t n, double t) { return find_closest(A, n, t); }
+ORC_EXPORT int orc_check_sides(const double *v1, const double *v2, const double *S, const double *n)
+{
+    return check_sides(v1, v2, S, n);
+}
