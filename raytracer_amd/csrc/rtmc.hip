@@ -1,0 +1,897 @@
+// rtmc.hip -- kernels and the C ABI of librtmc.so (gfx950 / MI355X).
+//
+// Host side: builds the device images of a scene (wavelength ids, absorption
+// coefficients per id, integer inverse-CDF thresholds), owns per-device
+// buffers and a stream, launches the kernels, folds the device tallies into the
+// caller's block.  Device side: see rtmc_device.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rtmc_device.h"
+
+using namespace rtmc;
+
+#define RTMC_API extern "C" __attribute__((visibility("default")))
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int TRACE_BLOCK = 256;      // 4 waves per workgroup
+constexpr uint32_t WORK_CHUNK = 1024; // photon ids a wave takes from the global counter at a time
+
+template <typename real>
+__device__ __forceinline__ Lds<real> stage_lds(const DevScene<real> &sc, unsigned char *smem, int n_acc)
+{
+    const uint32_t words = sc.lay.acc / 4;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = sc.lds_image[i];
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
+    for (int i = threadIdx.x; i < n_acc; i += blockDim.x) acc[i] = 0ull;
+    __syncthreads();
+    Lds<real> l;
+    l.elems = reinterpret_cast<const DevElem<real> *>(smem + sc.lay.elems);
+    l.mats = reinterpret_cast<const DevMat<real> *>(smem + sc.lay.mats);
+    l.abs = reinterpret_cast<const DevAbs<real> *>(smem + sc.lay.abs);
+    l.cdf = reinterpret_cast<const uint32_t *>(smem + sc.lay.cdf);
+    l.acc = acc;
+    return l;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Traces photon ids [first, first + n).  Every wave draws blocks of ids from
+// `work` and refills lanes whose photon has ended; the grid is sized to the
+// machine, not to n.
+template <typename real>
+__global__ void __launch_bounds__(TRACE_BLOCK)
+trace_kernel(DevScene<real> sc, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
+             unsigned long long *work)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n_acc = ACC_SCALARS + 3 * sc.n_el + sc.n_el * (int)sc.lay.n_src_lds;
+    Lds<real> lds = stage_lds(sc, smem, n_acc);
+
+    LdsTally<real> tally;
+    tally.acc = lds.acc; tally.hist = tl.hist; tally.wl = sc.wl; tally.eqeT = sc.eqeT;
+    tally.n_el = sc.n_el; tally.n_wid = (int)sc.lay.n_wid; tally.n_src_lds = (int)sc.lay.n_src_lds;
+
+    Photon<real> p;
+    Rng<real, false> g;
+    g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32);
+    g.id0 = g.id1 = g.ev = 0;
+    bool alive = false;
+    uint64_t chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool exhausted = false;
+    const uint32_t lane = threadIdx.x & 63;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(!alive);
+        if (idle != 0ull && !exhausted) {
+            if (chunk_next == chunk_end) {
+                unsigned long long s = 0;
+                if (lane == 0) s = atomicAdd(work, (unsigned long long)WORK_CHUNK);
+                uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)s);
+                uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
+                s = ((unsigned long long)hi << 32) | lo;
+                if (s >= n) exhausted = true;
+                else { chunk_next = s; chunk_end = (s + WORK_CHUNK < n) ? s + WORK_CHUNK : n; }
+            }
+            if (!exhausted) {
+                const uint32_t avail = (uint32_t)(chunk_end - chunk_next);
+                const uint32_t rank = lanes_below(idle);
+                if (!alive && rank < avail) {
+                    const uint64_t id = first + chunk_next + rank;
+                    g.id0 = (uint32_t)id; g.id1 = (uint32_t)(id >> 32); g.ev = 0;
+                    launch_photon(sc, lds, p, g);
+                    alive = true;
+                }
+                const uint32_t want = (uint32_t)__popcll(idle);
+                chunk_next += want < avail ? want : avail;
+            }
+        }
+        if (__ballot(alive) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        if (alive) {
+            if (!photon_step(sc, lds, p, g, tally)) {
+                count_fate(p, tally);
+                alive = false;
+            }
+        }
+    }
+
+    // flush the workgroup's accumulators
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
+        unsigned long long v = lds.acc[i];
+        if (v == 0ull) continue;
+        if (i < ACC_SCALARS) atomicAdd(&tl.scalars[i], v);
+        else if (i < ACC_SCALARS + sc.n_el) atomicAdd(&tl.bounce[i - ACC_SCALARS], v);
+        else if (i < ACC_SCALARS + 2 * sc.n_el) atomicAdd(&tl.spectral[i - ACC_SCALARS - sc.n_el], v);
+        else if (i < ACC_SCALARS + 3 * sc.n_el) atomicAdd(&tl.energy_fx[i - ACC_SCALARS - 2 * sc.n_el], v);
+        else {
+            int j = i - ACC_SCALARS - 3 * sc.n_el;
+            int el = j / (int)sc.lay.n_src_lds, wid = j % (int)sc.lay.n_src_lds;
+            atomicAdd(&tl.hist[(size_t)el * sc.lay.n_wid + wid], v);
+        }
+    }
+}
+
+// device view of an rtmc_photon_soa batch (wavelengths already mapped to ids)
+struct SoaDev {
+    double *loc[3], *dir[3], *efield[3], *old_point[3];
+    double *dist_left, *hit_distance;
+    int32_t *wid, *wid0, *material, *status, *last_element, *was_element, *reflected, *iterations,
+        *tape_pos;
+};
+
+// rtmc_step_tape: one lane per photon, variates from the tape.
+template <typename real>
+__global__ void __launch_bounds__(TRACE_BLOCK)
+step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int launch,
+                 const double *tape, const unsigned long long *tape_off, double *trace, int *overrun)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    Lds<real> lds = stage_lds(sc, smem, 0);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Rng<real, true> g;
+    g.tape = tape + tape_off[k];
+    g.end = (uint32_t)(tape_off[k + 1] - tape_off[k]);
+    g.pos = launch ? 0u : (uint32_t)b.tape_pos[k];
+    g.overrun = false;
+    Photon<real> p;
+    if (launch) {
+        launch_photon(sc, lds, p, g);
+    } else {
+        p.Lx = real(b.loc[0][k]); p.Ly = real(b.loc[1][k]); p.Lz = real(b.loc[2][k]);
+        p.Dx = real(b.dir[0][k]); p.Dy = real(b.dir[1][k]); p.Dz = real(b.dir[2][k]);
+        p.Ex = real(b.efield[0][k]); p.Ey = real(b.efield[1][k]); p.Ez = real(b.efield[2][k]);
+        p.oldx = real(b.old_point[0][k]); p.oldy = real(b.old_point[1][k]); p.oldz = real(b.old_point[2][k]);
+        p.dist = real(b.dist_left[k]);
+        p.hitd = M<real>::inf();
+        p.wid = b.wid[k]; p.wid0 = b.wid0[k];
+        p.mat = b.material[k]; p.status = b.status[k]; p.last_el = b.last_element[k];
+        p.was_el = b.was_element[k] != 0; p.reflected = b.reflected[k] != 0;
+        p.iter = b.iterations[k];
+        p.absorbed_once = false;
+        p.s_old = 0;
+        if (p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
+            const DevElem<real> &le = lds.elems[p.last_el];
+            double s = (double)le.nx * b.old_point[0][k] + (double)le.ny * b.old_point[1][k] +
+                       (double)le.nz * b.old_point[2][k] - (double)le.d0;
+            p.s_old = (s > 0) - (s < 0);
+        }
+    }
+    NoTally tally;
+    bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
+                   p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
+    for (uint32_t it = 0; it < n_steps && alive; it++) {
+        alive = photon_step(sc, lds, p, g, tally);
+        if (trace) {
+            double *r = trace + ((size_t)k * n_steps + it) * RTMC_TRACE_STRIDE;
+            r[0] = p.Lx; r[1] = p.Ly; r[2] = p.Lz; r[3] = p.Dx; r[4] = p.Dy; r[5] = p.Dz;
+            r[6] = p.Ex; r[7] = p.Ey; r[8] = p.Ez;
+            r[9] = sc.wl[p.wid]; r[10] = p.dist; r[11] = p.status; r[12] = p.mat;
+            r[13] = p.last_el; r[14] = p.hitd; r[15] = g.pos;
+        }
+    }
+    if (g.overrun) *overrun = 1;
+    b.loc[0][k] = p.Lx; b.loc[1][k] = p.Ly; b.loc[2][k] = p.Lz;
+    b.dir[0][k] = p.Dx; b.dir[1][k] = p.Dy; b.dir[2][k] = p.Dz;
+    b.efield[0][k] = p.Ex; b.efield[1][k] = p.Ey; b.efield[2][k] = p.Ez;
+    b.old_point[0][k] = p.oldx; b.old_point[1][k] = p.oldy; b.old_point[2][k] = p.oldz;
+    b.dist_left[k] = p.dist; b.hit_distance[k] = p.hitd;
+    b.wid[k] = p.wid; b.wid0[k] = p.wid0; b.material[k] = p.mat; b.status[k] = p.status;
+    b.last_element[k] = p.last_el; b.was_element[k] = p.was_el; b.reflected[k] = p.reflected;
+    b.iterations[k] = p.iter; b.tape_pos[k] = (int32_t)g.pos;
+}
+
+// rtmc_op_intersect: one lane per (ray, element)
+template <typename real>
+__global__ void intersect_kernel(DevScene<real> sc, uint32_t n, const double *loc, const double *dir,
+                                 double *out)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * sc.n_el) return;
+    const uint32_t k = (uint32_t)(idx / sc.n_el);
+    const int e = (int)(idx % sc.n_el);
+    real Lx = real(loc[3 * k]), Ly = real(loc[3 * k + 1]), Lz = real(loc[3 * k + 2]);
+    real Dx = real(dir[3 * k]), Dy = real(dir[3 * k + 1]), Dz = real(dir[3 * k + 2]);
+    real t;
+    bool ok = rect_hit(sc.elems[e], Lx, Ly, Lz, Dx, Dy, Dz, t);
+    const double nan = __builtin_nan("");
+    out[3 * idx] = ok ? (double)(Lx + t * Dx) : nan;
+    out[3 * idx + 1] = ok ? (double)(Ly + t * Dy) : nan;
+    out[3 * idx + 2] = ok ? (double)(Lz + t * Dz) : nan;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host: errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(RTMC_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// host: scene
+// ---------------------------------------------------------------------------
+namespace {
+
+struct HostTable {
+    std::vector<double> x, y;
+    bool same(const HostTable &o) const { return x == o.x && y == o.y; }
+};
+
+// nearest entry of an ascending table, RTUtils.py:15-22
+int64_t nearest_index(const std::vector<double> &A, double t)
+{
+    int64_t n = (int64_t)A.size();
+    int64_t idx = std::lower_bound(A.begin(), A.end(), t) - A.begin();
+    idx = std::min<int64_t>(std::max<int64_t>(idx, 1), n - 1);
+    if (t - A[idx - 1] < A[idx] - t) idx--;
+    return idx;
+}
+
+// interval-weighted cumulative distribution of an emission table:
+// RTUtils.py:152-158 then the cumulative sum numpy.random.choice searches
+std::vector<double> sampling_cdf(const HostTable &t, bool times_lambda)
+{
+    size_t n = t.x.size();
+    std::vector<double> w(n);
+    double total = 0;
+    for (size_t i = 0; i < n; i++) {
+        double v = times_lambda ? t.y[i] * t.x[i] : t.y[i];
+        if (i) v *= t.x[i] - t.x[i - 1];
+        w[i] = v;
+        total += v;
+    }
+    double run = 0;
+    for (size_t i = 0; i < n; i++) { run += w[i] / total; w[i] = run; }
+    for (size_t i = 0; i < n; i++) w[i] /= run;
+    return w;
+}
+
+// u < q  for u = v / 2^32 with integer v   <=>   v < ceil(q * 2^32);
+// the same integer serves "cdf entry <= u"  <=>  ceil(cdf * 2^32) <= v.
+uint32_t threshold32(double q)
+{
+    if (!(q > 0)) return 0u;  // also NaN
+    double s = std::ceil(q * 4294967296.0);
+    return s >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)s;
+}
+
+template <typename real>
+struct DeviceImage {
+    std::vector<DevElem<real>> elems;
+    std::vector<unsigned char> lds;  // elems | mats | abs | cdf
+    LdsLayout lay;
+    DevSource<real> src;
+};
+
+struct PerDevice {
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *elems32 = nullptr, *elems64 = nullptr, *lds32 = nullptr, *lds64 = nullptr;
+    double *wl = nullptr;
+    uint32_t *eqeT = nullptr;
+    unsigned long long *tallies = nullptr;  // scalars | bounce | spectral | energy | hist
+    unsigned long long *work = nullptr;
+    size_t tally_words = 0;
+    double last_ms = 0;
+    int max_blocks32 = 0, max_blocks64 = 0, n_cu = 0;
+};
+
+}  // namespace
+
+struct rtmc_scene {
+    int n_el = 0, n_mat = 0, n_eqe = 0, max_iter = 0;
+    std::vector<rtmc_element> elements;
+    std::vector<double> wl;         // wavelength of each id
+    std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
+    std::vector<int32_t> wid_bin;   // detector spectrum bin of each wavelength id
+    std::vector<int32_t> el_eqe;    // per element: eqe table or -1
+    DeviceImage<float> img32;
+    DeviceImage<double> img64;
+    std::mutex mu;
+    std::map<int, PerDevice> dev;
+};
+
+namespace {
+
+template <typename real>
+void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
+                 const std::vector<std::vector<double>> &cdfs, const std::vector<int> &cdf_off,
+                 const std::vector<int> &mat_cdfD, const std::vector<int> &mat_cdfA,
+                 const std::vector<int> &cdf_wid_off, const std::vector<int> &mat_abs_slot,
+                 const std::vector<HostTable> &absA, const std::vector<HostTable> &absD, int src_cdf,
+                 int n_src_lds, DeviceImage<real> &img)
+{
+    const int n_el = d->n_elements, n_mat = d->n_materials;
+    const int n_wid = (int)wl.size();
+    img.elems.resize(n_el);
+    for (int i = 0; i < n_el; i++) {
+        const rtmc_element &e = d->elements[i];
+        DevElem<real> &o = img.elems[i];
+        auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+        o.nx = (real)e.normal[0]; o.ny = (real)e.normal[1]; o.nz = (real)e.normal[2];
+        o.d0 = (real)dot(e.normal, e.support);
+        o.ax = (real)e.e1[0]; o.ay = (real)e.e1[1]; o.az = (real)e.e1[2];
+        o.c1 = (real)dot(e.e1, e.support);
+        o.bx = (real)e.e2[0]; o.by = (real)e.e2[1]; o.bz = (real)e.e2[2];
+        o.c2 = (real)dot(e.e2, e.support);
+        o.h1 = (real)e.half1; o.h2 = (real)e.half2;
+        o.type = e.type;
+        o.info = 0;
+        if (e.type == RTMC_TYPE_INTERFACE) o.info = e.material1 | (e.material2 << 8);
+        if (e.type == RTMC_TYPE_DUMP) o.info = e.eqe_table + 1;
+    }
+    std::vector<DevMat<real>> mats(n_mat);
+    int n_slots = 0;
+    for (int i = 0; i < n_mat; i++) {
+        const rtmc_material &m = d->materials[i];
+        DevMat<real> &o = mats[i];
+        memset(&o, 0, sizeof o);
+        o.n = (real)m.n;
+        o.flags = m.is_absorber ? 1 : 0;
+        o.name_id = m.name_id;
+        o.abs_slot = mat_abs_slot[i];
+        if (!m.is_absorber) continue;
+        n_slots = std::max(n_slots, o.abs_slot + 1);
+        double p[3], pa[3] = {0, 0, 0};
+        if (m.conc_a > 0) {  // MonteCarloFRET.py:67-77
+            o.n_p = 3;
+            p[0] = (1 - m.P_ET_DA) * m.Q_D; p[1] = (1 - m.P_ET_DA) * (1 - m.Q_D); p[2] = m.P_ET_DA;
+            pa[0] = (1 - m.P_ET_AD) * m.Q_A; pa[1] = (1 - m.P_ET_AD) * (1 - m.Q_A); pa[2] = m.P_ET_AD;
+        } else {  // MonteCarloFRET.py:82
+            o.n_p = 2;
+            p[0] = m.Q_D; p[1] = 1 - m.Q_D; p[2] = 0;
+        }
+        double sp = 0, spa = 0, c = 0, ca = 0;
+        for (int j = 0; j < o.n_p; j++) sp += p[j];
+        for (int j = 0; j < 3; j++) spa += pa[j];
+        for (int j = 0; j < 3; j++) {
+            c += p[j];
+            ca += pa[j];
+            o.pT[j] = j < o.n_p ? threshold32(c / sp) : 0xFFFFFFFFu;
+            o.pAT[j] = spa > 0 ? threshold32(ca / spa) : 0xFFFFFFFFu;
+        }
+        o.cdfD_off = cdf_off[mat_cdfD[i]]; o.cdfD_len = (int)cdfs[mat_cdfD[i]].size();
+        o.widD_off = cdf_wid_off[mat_cdfD[i]];
+        o.cdfA_off = cdf_off[mat_cdfA[i]]; o.cdfA_len = (int)cdfs[mat_cdfA[i]].size();
+        o.widA_off = cdf_wid_off[mat_cdfA[i]];
+    }
+    std::vector<DevAbs<real>> abs((size_t)n_slots * n_wid);
+    const double ln10 = std::log(10.0);
+    for (int i = 0; i < n_mat; i++) {
+        const rtmc_material &m = d->materials[i];
+        if (!m.is_absorber) continue;
+        const int slot = mat_abs_slot[i];
+        for (int w = 0; w < n_wid; w++) {
+            // PhotonObject.py:235-236 / 288-289
+            double ea = absA[i].y[nearest_index(absA[i].x, wl[w])];
+            double ed = absD[i].y[nearest_index(absD[i].x, wl[w])];
+            double b_a = m.conc_a * 1e-3 * m.emax_A * ln10 * std::max(1e-99, ea);
+            double b_d = m.conc_b * 1e-3 * m.emax_D * ln10 * std::max(1e-99, ed);
+            DevAbs<real> &o = abs[(size_t)slot * n_wid + w];
+            o.b_a = (real)b_a; o.b_d = (real)b_d;
+            o.coinT = threshold32(b_d / (b_d + b_a));
+            o.pad = 0;
+        }
+    }
+    std::vector<uint32_t> cdfT;
+    for (auto &c : cdfs)
+        for (double v : c) cdfT.push_back(threshold32(v));
+    if (cdfT.empty()) cdfT.push_back(0xFFFFFFFFu);
+
+    auto align = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    LdsLayout &lay = img.lay;
+    size_t off = 0;
+    lay.elems = (uint32_t)off; off = align(off + sizeof(DevElem<real>) * std::max(1, n_el));
+    lay.mats = (uint32_t)off; off = align(off + sizeof(DevMat<real>) * std::max(1, n_mat));
+    lay.abs = (uint32_t)off; off = align(off + sizeof(DevAbs<real>) * std::max<size_t>(1, abs.size()));
+    lay.cdf = (uint32_t)off; off = align(off + 4 * cdfT.size());
+    lay.acc = (uint32_t)off;
+    lay.n_wid = (uint32_t)n_wid;
+    lay.n_src_lds = (uint32_t)n_src_lds;
+    size_t n_acc = ACC_SCALARS + 3 * (size_t)n_el + (size_t)n_el * n_src_lds;
+    lay.total = (uint32_t)(off + 8 * n_acc);
+    img.lds.assign(off, 0);
+    if (n_el) memcpy(img.lds.data() + lay.elems, img.elems.data(), sizeof(DevElem<real>) * n_el);
+    if (n_mat) memcpy(img.lds.data() + lay.mats, mats.data(), sizeof(DevMat<real>) * n_mat);
+    if (!abs.empty()) memcpy(img.lds.data() + lay.abs, abs.data(), sizeof(DevAbs<real>) * abs.size());
+    memcpy(img.lds.data() + lay.cdf, cdfT.data(), 4 * cdfT.size());
+
+    const rtmc_source &s = d->source;
+    DevSource<real> &o = img.src;
+    memset(&o, 0, sizeof o);
+    double nrm = std::sqrt(s.direction[0] * s.direction[0] + s.direction[1] * s.direction[1] +
+                           s.direction[2] * s.direction[2]);
+    for (int j = 0; j < 3; j++) {
+        o.loc[j] = (real)s.location[j];
+        o.dir[j] = (real)(nrm > 0 ? s.direction[j] / nrm : 0.0);
+    }
+    for (int j = 0; j < 9; j++) o.frame[j] = (real)s.frame[j];
+    o.inv_scale = (real)(1.0 / s.scale_factor);
+    o.dir_mode = s.direction_mode; o.wl_mode = s.wavelength_mode; o.start_mat = s.start_material;
+    o.wid_fixed = 0;
+    if (src_cdf >= 0) { o.cdf_off = cdf_off[src_cdf]; o.cdf_len = (int)cdfs[src_cdf].size(); }
+}
+
+int get_table(const rtmc_scene_desc *d, rtmc_table ref, HostTable &t, const char *what)
+{
+    if (ref.len < 2 || ref.offset < 0 || ref.offset + 2 * ref.len > d->table_data_len)
+        return fail(RTMC_EINVAL, "%s: table (offset %lld, len %lld) outside table_data or shorter than 2 rows",
+                    what, (long long)ref.offset, (long long)ref.len);
+    t.x.resize(ref.len); t.y.resize(ref.len);
+    for (int64_t i = 0; i < ref.len; i++) {
+        t.x[i] = d->table_data[ref.offset + 2 * i];
+        t.y[i] = d->table_data[ref.offset + 2 * i + 1];
+    }
+    return RTMC_OK;
+}
+
+}  // namespace
+
+RTMC_API int rtmc_version(void) { return RTMC_ABI_VERSION; }
+RTMC_API const char *rtmc_last_error(void) { return g_error.c_str(); }
+
+RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
+{
+    if (!d || !out) return fail(RTMC_EINVAL, "null argument");
+    *out = nullptr;
+    if (d->abi_version != RTMC_ABI_VERSION)
+        return fail(RTMC_EINVAL, "description has ABI version %d, library %d", d->abi_version, RTMC_ABI_VERSION);
+    if (d->n_elements < 1 || d->n_elements > 255) return fail(RTMC_ELIMIT, "1..255 elements supported, got %d", d->n_elements);
+    if (d->n_materials < 1 || d->n_materials > 255) return fail(RTMC_ELIMIT, "1..255 materials supported, got %d", d->n_materials);
+    if (d->max_iterations < 1) return fail(RTMC_EINVAL, "max_iterations must be positive");
+    if (!d->elements || !d->materials) return fail(RTMC_EINVAL, "null element or material array");
+    const rtmc_source &src = d->source;
+    if (src.start_material < 0 || src.start_material >= d->n_materials) return fail(RTMC_EINVAL, "start material out of range");
+    if (!(src.scale_factor > 0)) return fail(RTMC_EINVAL, "scale_factor must be positive");
+    if (src.direction_mode != 0 && src.direction_mode != 1) return fail(RTMC_EINVAL, "unknown direction mode");
+    for (int i = 0; i < d->n_elements; i++) {
+        const rtmc_element &e = d->elements[i];
+        if (e.geometry != RTMC_GEOM_RECTANGLE)
+            return fail(RTMC_EUNSUPPORTED, "element %d: only rectangles are built so far (geometry code %d)", i, e.geometry);
+        if (e.type != RTMC_TYPE_MIRROR && e.type != RTMC_TYPE_INTERFACE && e.type != RTMC_TYPE_DUMP)
+            return fail(RTMC_EUNSUPPORTED, "element %d: element type code %d is not built so far", i, e.type);
+        if (e.type == RTMC_TYPE_INTERFACE &&
+            (e.material1 < 0 || e.material1 >= d->n_materials || e.material2 < 0 || e.material2 >= d->n_materials))
+            return fail(RTMC_EINVAL, "element %d: interface material out of range", i);
+        if (e.type == RTMC_TYPE_DUMP && e.eqe_table >= d->n_tables)
+            return fail(RTMC_EINVAL, "element %d: detection table out of range", i);
+    }
+
+    std::vector<HostTable> absA(d->n_materials), absD(d->n_materials);
+    std::vector<HostTable> em;       // unique emission / source tables
+    std::vector<int> em_kind;        // 0 emission, 1 source spectrum
+    std::vector<int> mat_cdfD(d->n_materials, -1), mat_cdfA(d->n_materials, -1), mat_abs_slot(d->n_materials, -1);
+    int src_cdf = -1, n_slots = 0;
+    std::vector<double> wl;
+    std::vector<int> cdf_wid_off;
+
+    auto add_table = [&](const HostTable &t, int kind) {
+        for (size_t i = 0; i < em.size(); i++)
+            if (em_kind[i] == kind && em[i].same(t)) return (int)i;
+        em.push_back(t);
+        em_kind.push_back(kind);
+        cdf_wid_off.push_back((int)wl.size());
+        wl.insert(wl.end(), t.x.begin(), t.x.end());
+        return (int)em.size() - 1;
+    };
+
+    int n_src_lds = 0;
+    if (src.wavelength_mode == 0) {
+        wl.push_back(src.wavelength);  // id 0
+        n_src_lds = 1;
+    } else if (src.wavelength_mode == 1) {
+        HostTable t;
+        int rc = get_table(d, src.spectrum, t, "source spectrum");
+        if (rc) return rc;
+        src_cdf = add_table(t, 1);
+    } else
+        return fail(RTMC_EINVAL, "unknown wavelength mode");
+
+    for (int i = 0; i < d->n_materials; i++) {
+        const rtmc_material &m = d->materials[i];
+        if (!m.is_absorber) continue;
+        if (m.is_aligned) return fail(RTMC_EUNSUPPORTED, "material %d: aligned dyes are not built so far", i);
+        int rc;
+        HostTable eD, eA;
+        if ((rc = get_table(d, m.abs_A, absA[i], "abs_A")) || (rc = get_table(d, m.abs_D, absD[i], "abs_D")) ||
+            (rc = get_table(d, m.em_A, eA, "em_A")) || (rc = get_table(d, m.em_D, eD, "em_D")))
+            return rc;
+        mat_cdfD[i] = add_table(eD, 0);
+        mat_cdfA[i] = add_table(eA, 0);
+        mat_abs_slot[i] = n_slots++;
+    }
+    if (wl.size() > 65535) return fail(RTMC_ELIMIT, "%zu distinct wavelengths, at most 65535 supported", wl.size());
+
+    std::vector<std::vector<double>> cdfs(em.size());
+    std::vector<int> cdf_off(em.size());
+    int run = 0;
+    for (size_t i = 0; i < em.size(); i++) {
+        cdfs[i] = sampling_cdf(em[i], em_kind[i] == 1);
+        cdf_off[i] = run;
+        run += (int)cdfs[i].size();
+    }
+
+    rtmc_scene *s = new rtmc_scene;
+    s->n_el = d->n_elements; s->n_mat = d->n_materials; s->n_eqe = d->n_tables; s->max_iter = d->max_iterations;
+    s->elements.assign(d->elements, d->elements + d->n_elements);
+    s->wl = wl;
+    s->el_eqe.resize(s->n_el);
+    for (int i = 0; i < s->n_el; i++) s->el_eqe[i] = d->elements[i].type == RTMC_TYPE_DUMP ? d->elements[i].eqe_table : -1;
+    // detector bin of every wavelength: nearest of 200..3999 nm, Elements.py:159
+    std::vector<double> bins(RTMC_SPECTRUM_BINS);
+    for (int i = 0; i < RTMC_SPECTRUM_BINS; i++) bins[i] = RTMC_SPECTRUM_FIRST_NM + i;
+    s->wid_bin.resize(wl.size());
+    for (size_t w = 0; w < wl.size(); w++) s->wid_bin[w] = (int32_t)nearest_index(bins, wl[w]);
+    // detection thresholds, Elements.py:164
+    s->eqeT.assign(std::max<size_t>(1, (size_t)d->n_tables * wl.size()), 0xFFFFFFFFu);
+    for (int t = 0; t < d->n_tables; t++) {
+        HostTable q;
+        int rc = get_table(d, d->tables[t], q, "detection spectrum");
+        if (rc) { delete s; return rc; }
+        for (size_t w = 0; w < wl.size(); w++)
+            s->eqeT[(size_t)t * wl.size() + w] = threshold32(q.y[nearest_index(q.x, wl[w])]);
+    }
+    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, n_src_lds, s->img32);
+    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, n_src_lds, s->img64);
+    if (s->img32.lay.total > 160 * 1024) {
+        size_t need = s->img32.lay.total;
+        delete s;
+        return fail(RTMC_ELIMIT, "scene tables need %zu bytes of LDS, 163840 available", need);
+    }
+    *out = s;
+    return RTMC_OK;
+}
+
+static void free_device(PerDevice &p)
+{
+    if (!p.ready) return;
+    void *bufs[] = {p.elems32, p.elems64, p.lds32, p.lds64, p.wl, p.eqeT, p.tallies, p.work};
+    for (void *b : bufs) (void)hipFree(b);
+    if (p.ev0) (void)hipEventDestroy(p.ev0);
+    if (p.ev1) (void)hipEventDestroy(p.ev1);
+    if (p.stream) (void)hipStreamDestroy(p.stream);
+    p.ready = false;
+}
+
+RTMC_API void rtmc_scene_destroy(rtmc_scene *s)
+{
+    if (!s) return;
+    for (auto &kv : s->dev) {
+        if (hipSetDevice(kv.first) == hipSuccess) free_device(kv.second);
+    }
+    delete s;
+}
+
+RTMC_API int rtmc_scene_wavelengths(const rtmc_scene *s, int64_t *count, double *values, int64_t capacity)
+{
+    if (!s || !count) return fail(RTMC_EINVAL, "null argument");
+    *count = (int64_t)s->wl.size();
+    if (values) {
+        if (capacity < *count) return fail(RTMC_EINVAL, "capacity %lld < %lld", (long long)capacity, (long long)*count);
+        memcpy(values, s->wl.data(), sizeof(double) * s->wl.size());
+    }
+    return RTMC_OK;
+}
+
+// upload the scene to `device` on first use; leaves that device current
+static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
+{
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(RTMC_EINVAL, "device %d out of range (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    std::lock_guard<std::mutex> lock(s->mu);
+    PerDevice &p = s->dev[device];
+    *out = &p;
+    if (p.ready) return RTMC_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&p.ev0));
+    HIP_TRY(hipEventCreate(&p.ev1));
+    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    HIP_TRY(upload(&p.elems32, s->img32.elems.data(), sizeof(DevElem<float>) * s->n_el));
+    HIP_TRY(upload(&p.elems64, s->img64.elems.data(), sizeof(DevElem<double>) * s->n_el));
+    HIP_TRY(upload(&p.lds32, s->img32.lds.data(), s->img32.lds.size()));
+    HIP_TRY(upload(&p.lds64, s->img64.lds.data(), s->img64.lds.size()));
+    HIP_TRY(upload((void **)&p.wl, s->wl.data(), sizeof(double) * s->wl.size()));
+    HIP_TRY(upload((void **)&p.eqeT, s->eqeT.data(), 4 * s->eqeT.size()));
+    p.tally_words = ACC_SCALARS + 3 * (size_t)s->n_el + (size_t)s->n_el * s->wl.size();
+    HIP_TRY(hipMalloc((void **)&p.tallies, 8 * p.tally_words));
+    HIP_TRY(hipMalloc((void **)&p.work, 8));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    p.n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipFuncSetAttribute((const void *)trace_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
+    HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks32, trace_kernel<float>, TRACE_BLOCK, s->img32.lay.total));
+    if (s->img64.lay.total <= 160 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void *)trace_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
+        HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace_kernel<double>, TRACE_BLOCK, s->img64.lay.total));
+    }
+    p.ready = true;
+    return RTMC_OK;
+}
+
+template <typename real>
+static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, const DeviceImage<real> &img)
+{
+    DevScene<real> sc;
+    sc.elems = (const DevElem<real> *)(sizeof(real) == 4 ? p.elems32 : p.elems64);
+    sc.lds_image = (const uint32_t *)(sizeof(real) == 4 ? p.lds32 : p.lds64);
+    sc.wl = p.wl;
+    sc.eqeT = p.eqeT;
+    sc.src = img.src;
+    sc.lay = img.lay;
+    sc.n_el = s->n_el; sc.n_mat = s->n_mat; sc.max_iter = s->max_iter;
+    return sc;
+}
+
+RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                        uint64_t n_photons, rtmc_tallies *out)
+{
+    if (!s || !out) return fail(RTMC_EINVAL, "null argument");
+    if (out->n_elements != s->n_el) return fail(RTMC_EINVAL, "tally block is for %d elements, scene has %d", out->n_elements, s->n_el);
+    if (!out->counter || !out->spectral || !out->bounce || !out->energy_fx || !out->spectrum)
+        return fail(RTMC_EINVAL, "tally block has a null array");
+    if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
+    if (first_photon + n_photons < first_photon) return fail(RTMC_EINVAL, "photon id range wraps");
+    PerDevice *pp;
+    int rc = prepare_device(s, device, &pp);
+    if (rc) return rc;
+    PerDevice &p = *pp;
+    if (n_photons == 0) return RTMC_OK;
+    const bool f32 = precision == RTMC_F32;
+    const size_t lds_bytes = f32 ? s->img32.lay.total : s->img64.lay.total;
+    const int per_cu = f32 ? p.max_blocks32 : p.max_blocks64;
+    if (per_cu < 1) return fail(RTMC_ELIMIT, "scene tables (%zu bytes) do not fit the LDS in this precision", lds_bytes);
+
+    DevTallies tl;
+    tl.scalars = p.tallies;
+    tl.bounce = tl.scalars + ACC_SCALARS;
+    tl.spectral = tl.bounce + s->n_el;
+    tl.energy_fx = tl.spectral + s->n_el;
+    tl.hist = tl.energy_fx + s->n_el;
+
+    // enough waves to fill the machine, never more than there are blocks of ids
+    uint64_t wanted = (n_photons + 63) / 64;                          // waves
+    wanted = (wanted + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64);    // workgroups
+    uint64_t resident = (uint64_t)p.n_cu * (uint64_t)per_cu;
+    unsigned grid = (unsigned)std::max<uint64_t>(1, std::min(wanted, resident));
+
+    HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
+    HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
+    HIP_TRY(hipEventRecord(p.ev0, p.stream));
+    if (f32)
+        hipLaunchKernelGGL(trace_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                           device_scene<float>(s, p, s->img32), tl, seed, first_photon, n_photons, p.work);
+    else
+        hipLaunchKernelGGL(trace_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                           device_scene<double>(s, p, s->img64), tl, seed, first_photon, n_photons, p.work);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p.ev1, p.stream));
+    std::vector<unsigned long long> host(p.tally_words);
+    HIP_TRY(hipMemcpyAsync(host.data(), p.tallies, 8 * p.tally_words, hipMemcpyDeviceToHost, p.stream));
+    HIP_TRY(hipStreamSynchronize(p.stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, p.ev0, p.ev1));
+    p.last_ms = ms;
+
+    const unsigned long long *sc = host.data();
+    const unsigned long long *bounce = sc + ACC_SCALARS, *spectral = bounce + s->n_el,
+                             *energy = spectral + s->n_el, *hist = energy + s->n_el;
+    out->n_photons += sc[ACC_PHOTONS];
+    out->n_steps += sc[ACC_STEPS];
+    out->n_absorbed_once += sc[ACC_ABS_ONCE];
+    out->n_absorptions += sc[ACC_ABSORPTIONS];
+    out->n_internal_converted += sc[ACC_IC];
+    out->n_dumped += sc[ACC_DUMPED];
+    out->n_capped += sc[ACC_CAPPED];
+    out->n_lost += sc[ACC_LOST];
+    out->n_stale_steps += sc[ACC_STALE];
+    const size_t n_wid = s->wl.size();
+    for (int e = 0; e < s->n_el; e++) {
+        out->bounce[e] += bounce[e];
+        out->energy_fx[e] += energy[e];
+        unsigned long long total = 0;
+        for (size_t w = 0; w < n_wid; w++) {
+            unsigned long long c = hist[(size_t)e * n_wid + w];
+            if (!c) continue;
+            total += c;
+            out->spectrum[(size_t)e * RTMC_SPECTRUM_BINS + s->wid_bin[w]] += c;
+        }
+        out->counter[e] += total;
+        // Elements.py:161-165: without a detection table every photon counts
+        out->spectral[e] += s->el_eqe[e] >= 0 ? spectral[e] : total;
+    }
+    return RTMC_OK;
+}
+
+RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device)
+{
+    if (!s) return -1.0;
+    auto it = s->dev.find(device);
+    return it == s->dev.end() ? -1.0 : it->second.last_ms;
+}
+
+namespace {
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    ~DeviceBuffer() { if (ptr) (void)hipFree(ptr); }
+};
+}  // namespace
+
+RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
+                              const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
+                              double *trace)
+{
+    if (!s || !b || !tape || !tape_off) return fail(RTMC_EINVAL, "null argument");
+    if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
+    if (n == 0) return RTMC_OK;
+    for (uint32_t k = 0; k < n; k++) {
+        if (tape_off[k + 1] < tape_off[k]) return fail(RTMC_EINVAL, "tape offsets must ascend");
+        if (tape_off[k + 1] - tape_off[k] > 0x7FFFFFFFull) return fail(RTMC_ELIMIT, "tape segment too long");
+    }
+    PerDevice *pp;
+    int rc = prepare_device(s, device, &pp);
+    if (rc) return rc;
+    PerDevice &p = *pp;
+    const bool f32 = precision == RTMC_F32;
+    const size_t lds_bytes = f32 ? s->img32.lay.acc : s->img64.lay.acc;
+    if (lds_bytes > 160 * 1024) return fail(RTMC_ELIMIT, "scene tables do not fit the LDS in this precision");
+
+    // wavelengths -> ids
+    std::vector<int32_t> wid(n, 0), wid0(n, 0);
+    if (!launch) {
+        std::map<double, int32_t> ids;
+        for (size_t w = s->wl.size(); w-- > 0;) ids[s->wl[w]] = (int32_t)w;
+        for (uint32_t k = 0; k < n; k++) {
+            auto a = ids.find(b->wavelength[k]), c = ids.find(b->start_wavelength[k]);
+            if (a == ids.end() || c == ids.end())
+                return fail(RTMC_EINVAL, "photon %u carries a wavelength that is neither a source line nor an emission-table row", k);
+            wid[k] = a->second; wid0[k] = c->second;
+            if (b->material[k] < 0 || b->material[k] >= s->n_mat) return fail(RTMC_EINVAL, "photon %u: material out of range", k);
+            if (b->last_element[k] < -1 || b->last_element[k] >= s->n_el) return fail(RTMC_EINVAL, "photon %u: element out of range", k);
+            uint64_t seg = tape_off[k + 1] - tape_off[k];
+            if (b->tape_pos[k] < 0 || (uint64_t)b->tape_pos[k] > seg) return fail(RTMC_EINVAL, "photon %u: tape position outside its segment", k);
+        }
+    }
+    const size_t nd = 14, ni = 9;  // double / int32 columns
+    const size_t tape_len = tape_off[n];
+    DeviceBuffer dbuf, ibuf, tbuf, obuf, trbuf, ovbuf;
+    HIP_TRY(hipMalloc(&dbuf.ptr, 8 * nd * n));
+    HIP_TRY(hipMalloc(&ibuf.ptr, 4 * ni * n));
+    HIP_TRY(hipMalloc(&tbuf.ptr, 8 * std::max<size_t>(tape_len, 1)));
+    HIP_TRY(hipMalloc(&obuf.ptr, 8 * (n + 1)));
+    HIP_TRY(hipMalloc(&ovbuf.ptr, 4));
+    if (trace) HIP_TRY(hipMalloc(&trbuf.ptr, 8 * (size_t)n * n_steps * RTMC_TRACE_STRIDE));
+    double *dd = (double *)dbuf.ptr;
+    int32_t *ii = (int32_t *)ibuf.ptr;
+    SoaDev sd;
+    const double *hsrc[nd];
+    for (int j = 0; j < 3; j++) {
+        sd.loc[j] = dd + (size_t)(0 + j) * n; hsrc[0 + j] = b->loc[j];
+        sd.dir[j] = dd + (size_t)(3 + j) * n; hsrc[3 + j] = b->dir[j];
+        sd.efield[j] = dd + (size_t)(6 + j) * n; hsrc[6 + j] = b->efield[j];
+        sd.old_point[j] = dd + (size_t)(9 + j) * n; hsrc[9 + j] = b->old_point[j];
+    }
+    sd.dist_left = dd + (size_t)12 * n; hsrc[12] = b->dist_left;
+    sd.hit_distance = dd + (size_t)13 * n; hsrc[13] = b->hit_distance;
+    int32_t *icols[ni];
+    for (size_t j = 0; j < ni; j++) icols[j] = ii + j * n;
+    sd.wid = icols[0]; sd.wid0 = icols[1]; sd.material = icols[2]; sd.status = icols[3];
+    sd.last_element = icols[4]; sd.was_element = icols[5]; sd.reflected = icols[6];
+    sd.iterations = icols[7]; sd.tape_pos = icols[8];
+    const int32_t *isrc[ni] = {wid.data(), wid0.data(), b->material, b->status, b->last_element,
+                               b->was_element, b->reflected, b->iterations, b->tape_pos};
+    if (!launch) {
+        for (size_t j = 0; j < nd; j++) HIP_TRY(hipMemcpyAsync(dd + j * n, hsrc[j], 8 * (size_t)n, hipMemcpyHostToDevice, p.stream));
+        for (size_t j = 0; j < ni; j++) HIP_TRY(hipMemcpyAsync(icols[j], isrc[j], 4 * (size_t)n, hipMemcpyHostToDevice, p.stream));
+    }
+    HIP_TRY(hipMemcpyAsync(tbuf.ptr, tape, 8 * tape_len, hipMemcpyHostToDevice, p.stream));
+    HIP_TRY(hipMemcpyAsync(obuf.ptr, tape_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, p.stream));
+    HIP_TRY(hipMemsetAsync(ovbuf.ptr, 0, 4, p.stream));
+    if (trace) HIP_TRY(hipMemcpyAsync(trbuf.ptr, trace, 8 * (size_t)n * n_steps * RTMC_TRACE_STRIDE, hipMemcpyHostToDevice, p.stream));
+    const unsigned grid = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
+    if (f32)
+        hipLaunchKernelGGL(step_tape_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                           device_scene<float>(s, p, s->img32), sd, n, n_steps, launch, (const double *)tbuf.ptr,
+                           (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr);
+    else
+        hipLaunchKernelGGL(step_tape_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                           device_scene<double>(s, p, s->img64), sd, n, n_steps, launch, (const double *)tbuf.ptr,
+                           (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr);
+    HIP_TRY(hipGetLastError());
+    // results
+    double *hdst[nd];
+    for (int j = 0; j < 3; j++) { hdst[j] = b->loc[j]; hdst[3 + j] = b->dir[j]; hdst[6 + j] = b->efield[j]; hdst[9 + j] = b->old_point[j]; }
+    hdst[12] = b->dist_left; hdst[13] = b->hit_distance;
+    for (size_t j = 0; j < nd; j++) HIP_TRY(hipMemcpyAsync(hdst[j], dd + j * n, 8 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
+    int32_t *idst[ni] = {wid.data(), wid0.data(), b->material, b->status, b->last_element,
+                         b->was_element, b->reflected, b->iterations, b->tape_pos};
+    for (size_t j = 0; j < ni; j++) HIP_TRY(hipMemcpyAsync(idst[j], icols[j], 4 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
+    if (trace) HIP_TRY(hipMemcpyAsync(trace, trbuf.ptr, 8 * (size_t)n * n_steps * RTMC_TRACE_STRIDE, hipMemcpyDeviceToHost, p.stream));
+    int overrun = 0;
+    HIP_TRY(hipMemcpyAsync(&overrun, ovbuf.ptr, 4, hipMemcpyDeviceToHost, p.stream));
+    HIP_TRY(hipStreamSynchronize(p.stream));
+    for (uint32_t k = 0; k < n; k++) {
+        b->wavelength[k] = s->wl[wid[k]];
+        b->start_wavelength[k] = s->wl[wid0[k]];
+    }
+    if (overrun) return fail(RTMC_EINVAL, "variate tape exhausted");
+    return RTMC_OK;
+}
+
+RTMC_API int rtmc_op_intersect(rtmc_scene *s, int device, int precision, uint32_t n, const double *loc,
+                                 const double *dir, double *out_points)
+{
+    if (!s || !loc || !dir || !out_points) return fail(RTMC_EINVAL, "null argument");
+    if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
+    if (n == 0) return RTMC_OK;
+    PerDevice *pp;
+    int rc = prepare_device(s, device, &pp);
+    if (rc) return rc;
+    PerDevice &p = *pp;
+    DeviceBuffer dl, ddir, dout;
+    const size_t total = (size_t)n * s->n_el;
+    HIP_TRY(hipMalloc(&dl.ptr, 24 * (size_t)n));
+    HIP_TRY(hipMalloc(&ddir.ptr, 24 * (size_t)n));
+    HIP_TRY(hipMalloc(&dout.ptr, 24 * total));
+    HIP_TRY(hipMemcpyAsync(dl.ptr, loc, 24 * (size_t)n, hipMemcpyHostToDevice, p.stream));
+    HIP_TRY(hipMemcpyAsync(ddir.ptr, dir, 24 * (size_t)n, hipMemcpyHostToDevice, p.stream));
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (precision == RTMC_F32)
+        hipLaunchKernelGGL(intersect_kernel<float>, dim3(grid), dim3(256), 0, p.stream, device_scene<float>(s, p, s->img32),
+                           n, (const double *)dl.ptr, (const double *)ddir.ptr, (double *)dout.ptr);
+    else
+        hipLaunchKernelGGL(intersect_kernel<double>, dim3(grid), dim3(256), 0, p.stream, device_scene<double>(s, p, s->img64),
+                           n, (const double *)dl.ptr, (const double *)ddir.ptr, (double *)dout.ptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_points, dout.ptr, 24 * total, hipMemcpyDeviceToHost, p.stream));
+    HIP_TRY(hipStreamSynchronize(p.stream));
+    return RTMC_OK;
+}

@@ -1,0 +1,654 @@
+// rtmc_device.h -- device-side photon transport for gfx950 (MI355X).
+//
+// One photon lives in the registers of one lane from launch to its end; a
+// wave keeps its 64 lanes busy by handing new photon ids to lanes whose
+// photon has ended (ballot + prefix count).  Everything a photon looks up is
+// staged in LDS at kernel start: the element records used by the optical
+// operations, the media, and per wavelength-id the absorption coefficients and
+// inverse-CDF thresholds.  The element records used by the nearest-hit search
+// are read with wave-uniform indices so that they travel through the scalar
+// cache into SGPRs.
+//
+// The code is a template over the arithmetic type: `float` is the production
+// instantiation, `double` exists to validate the logic against the float64
+// CPU checker.  It is also a template over the source of variates: Philox
+// (production) or a tape of recorded values (parity tests).
+//
+// Reference file:line citations name the statement of mohrezaeib/RayTracer
+// that a routine stands for.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtmc.h"
+
+namespace rtmc {
+
+// ---------------------------------------------------------------------------
+// records shared between host (scene builder) and device
+// ---------------------------------------------------------------------------
+
+// One element as the nearest-hit search and the optical operation see it.
+// plane: n.x = d0; in-plane coordinates t1 = a.x - c1, t2 = b.x - c2.
+template <typename real>
+struct DevElem {
+    real nx, ny, nz, d0;
+    real ax, ay, az, c1;
+    real bx, by, bz, c2;
+    real h1, h2;
+    int32_t type;  // RTMC_TYPE_*
+    int32_t info;  // interface: material1 | material2 << 8; dump: eqe table + 1
+};
+
+// One medium.
+template <typename real>
+struct DevMat {
+    real n;
+    int32_t flags;     // bit 0: absorber
+    int32_t name_id;
+    int32_t abs_slot;  // row block in the absorption table, -1 if not an absorber
+    int32_t n_p;       // 3: donor pathways incl. transfer, 2: no acceptor present
+    uint32_t pT[3];    // cumulative thresholds of the donor pathways (x 2^32)
+    uint32_t pAT[3];   // acceptor pathways
+    int32_t cdfD_off, cdfD_len, widD_off;  // donor emission: threshold table, first wavelength id
+    int32_t cdfA_off, cdfA_len, widA_off;  // acceptor emission
+    int32_t pad0, pad1;
+};
+
+// Absorption data of one (absorbing medium, wavelength id).
+template <typename real>
+struct DevAbs {
+    real b_a;        // acceptor attenuation coefficient [1/cm] (PhotonObject.py:288)
+    real b_d;        // donor                                   (PhotonObject.py:289)
+    uint32_t coinT;  // ceil(b_d / (b_d + b_a) * 2^32): "absorbed by the donor" threshold
+    uint32_t pad;
+};
+
+template <typename real>
+struct DevSource {
+    real loc[3];
+    real dir[3];     // unit (strict mode)
+    real frame[9];   // hemisphere frame, row-major
+    real inv_scale;  // 1 / ScaleFactor
+    int32_t dir_mode, wl_mode, start_mat, wid_fixed;
+    int32_t cdf_off, cdf_len;  // source spectrum thresholds; wavelength id = row
+};
+
+// Offsets (in bytes) into the LDS image.
+struct LdsLayout {
+    uint32_t elems, mats, abs, cdf, acc, total;
+    uint32_t n_wid;      // wavelength ids
+    uint32_t n_src_lds;  // wavelength ids whose detector histogram is kept in LDS
+};
+
+// Accumulators a workgroup keeps in LDS and flushes once (all uint64).
+// layout: scalars[ACC_SCALARS] bounce[n_el] spectral[n_el] energy[n_el] hist_src[n_el*n_src_lds]
+enum { ACC_STEPS = 0, ACC_ABS_ONCE, ACC_ABSORPTIONS, ACC_IC, ACC_DUMPED, ACC_CAPPED, ACC_LOST,
+       ACC_STALE, ACC_PHOTONS, ACC_SCALARS };
+
+template <typename real>
+struct DevScene {
+    const DevElem<real> *elems;  // global copy for wave-uniform reads
+    const uint32_t *lds_image;   // elems | mats | abs | cdf, copied to LDS by every workgroup
+    const double *wl;            // wavelength of each id
+    const uint32_t *eqeT;        // [n_eqe][n_wid] detection thresholds
+    DevSource<real> src;
+    LdsLayout lay;
+    int32_t n_el, n_mat, max_iter;
+};
+
+struct DevTallies {
+    unsigned long long *scalars;    // ACC_SCALARS
+    unsigned long long *bounce;     // n_el
+    unsigned long long *spectral;   // n_el
+    unsigned long long *energy_fx;  // n_el
+    unsigned long long *hist;       // n_el * n_wid
+};
+
+#if defined(__HIPCC__)
+// ---------------------------------------------------------------------------
+// arithmetic helpers
+// ---------------------------------------------------------------------------
+template <typename real> struct M;
+template <> struct M<float> {
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
+    static __device__ __forceinline__ float log(float x) { return ::logf(x); }
+    static __device__ __forceinline__ void sincospi(float x, float *s, float *c) { ::sincospif(x, s, c); }
+    static __device__ __forceinline__ float huge() { return 3.0e38f; }
+    static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static constexpr float self_hit_eps = 0.0f;
+};
+template <> struct M<double> {
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / __builtin_sqrt(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+    static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ void sincospi(double x, double *s, double *c) { ::sincospi(x, s, c); }
+    static __device__ __forceinline__ double huge() { return 1.0e300; }
+    static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static constexpr double self_hit_eps = 1e-8;  // RayTrace.py:134
+};
+
+template <typename real>
+__device__ __forceinline__ int sgn_i(real x) { return (x > real(0)) - (x < real(0)); }
+
+// ---------------------------------------------------------------------------
+// variates
+// ---------------------------------------------------------------------------
+// Philox4x32-10.  key = (seed lo, seed hi); counter = (photon id lo, hi, event, 0).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// A draw *event* is one place of the photon's life where variates are needed
+// (launch polarisation, one interface operation, one absorption, ...).  In
+// Philox mode every event owns one counter value, i.e. four fresh 32-bit
+// words; a word is used as a 24-bit uniform k/2^24.  In tape mode the values
+// are read sequentially in the order the reference draws them.
+template <typename real, bool TAPE>
+struct Rng;
+
+template <typename real>
+struct Rng<real, false> {
+    uint32_t k0, k1, id0, id1, ev;
+    uint32_t w[4];
+    __device__ __forceinline__ void skip() { ev++; }
+    __device__ __forceinline__ void event() { philox4x32_10(id0, id1, ev, 0u, k0, k1, w); ev++; }
+    // the uniform as an integer: floor(u * 2^32)
+    __device__ __forceinline__ uint32_t u32(int slot) { return w[slot] & 0xFFFFFF00u; }
+    __device__ __forceinline__ real uniform(int slot) { return real(w[slot] >> 8) * real(1.0 / 16777216.0); }
+    // unit exponential, numpy legacy form -log(1 - U)
+    __device__ __forceinline__ real expo(int slot) { return -M<real>::log(real(1) - uniform(slot)); }
+    __device__ __forceinline__ void normal3(real &a, real &b, real &c)
+    {
+        real r0 = M<real>::sqrt(real(-2) * M<real>::log((real(w[0] >> 8) + real(1)) * real(1.0 / 16777216.0)));
+        real r1 = M<real>::sqrt(real(-2) * M<real>::log((real(w[2] >> 8) + real(1)) * real(1.0 / 16777216.0)));
+        real s0, c0, s1, c1;
+        M<real>::sincospi(real(2) * uniform(1), &s0, &c0);
+        M<real>::sincospi(real(2) * uniform(3), &s1, &c1);
+        a = r0 * c0; b = r0 * s0; c = r1 * c1;
+        (void)s1;
+    }
+    __device__ __forceinline__ bool consume_dead_draws() const { return false; }
+};
+
+template <typename real>
+struct Rng<real, true> {
+    const double *tape;
+    uint32_t pos, end;
+    bool overrun;
+    __device__ __forceinline__ double next()
+    {
+        if (pos >= end) { overrun = true; return 0.5; }
+        return tape[pos++];
+    }
+    __device__ __forceinline__ void skip() {}
+    __device__ __forceinline__ void event() {}
+    __device__ __forceinline__ uint32_t u32(int)
+    {
+        double v = next() * 4294967296.0;
+        return v >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)v;
+    }
+    __device__ __forceinline__ real uniform(int) { return real(next()); }
+    __device__ __forceinline__ real expo(int) { return real(next()); }
+    __device__ __forceinline__ void normal3(real &a, real &b, real &c)
+    {
+        a = real(next()); b = real(next()); c = real(next());
+    }
+    // the reference draws a free path even for a photon that was just lost to
+    // internal conversion (PhotonObject.py:250/258); the tape holds that value
+    __device__ __forceinline__ bool consume_dead_draws() const { return true; }
+};
+
+// ---------------------------------------------------------------------------
+// photon
+// ---------------------------------------------------------------------------
+template <typename real>
+struct Photon {
+    real Lx, Ly, Lz, Dx, Dy, Dz, Ex, Ey, Ez;
+    real dist;       // DistanceLeftToAbsorption
+    real hitd;       // SmallestDistance of the last iteration
+    real oldx, oldy, oldz;  // RayTrace.OldPoint (kept for the step-wise interface only)
+    int32_t wid, wid0;
+    int32_t mat;
+    int32_t last_el;  // RayTrace.FirstEl, -1 none
+    int32_t s_old;    // side of RayTrace.OldPoint w.r.t. the last operation plane: -1, 0, +1
+    int32_t status;
+    int32_t iter;
+    bool was_el, reflected, absorbed_once;
+};
+
+// Views into the LDS image.
+template <typename real>
+struct Lds {
+    const DevElem<real> *elems;
+    const DevMat<real> *mats;
+    const DevAbs<real> *abs;
+    const uint32_t *cdf;
+    unsigned long long *acc;
+};
+
+// number of thresholds <= v  ==  numpy.searchsorted(cdf, u, side='right')
+__device__ __forceinline__ int cdf_pick(const uint32_t *T, int n, uint32_t v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (T[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo < n ? lo : n - 1;
+}
+
+template <typename real>
+__device__ __forceinline__ void normalize3(real &x, real &y, real &z)
+{
+    real s = M<real>::rsqrt(x * x + y * y + z * z);
+    x *= s; y *= s; z *= s;
+}
+
+// PhotonObject.py:107-114 UpdatePolarizationRandom: E = unit(D x unit(v)), v ~ N(0,1)^3
+template <typename real, bool TAPE>
+__device__ __forceinline__ void random_polarization(Photon<real> &p, Rng<real, TAPE> &g)
+{
+    real vx, vy, vz;
+    g.event();
+    g.normal3(vx, vy, vz);
+    normalize3(vx, vy, vz);
+    real ex = p.Dy * vz - p.Dz * vy, ey = p.Dz * vx - p.Dx * vz, ez = p.Dx * vy - p.Dy * vx;
+    normalize3(ex, ey, ez);
+    p.Ex = ex; p.Ey = ey; p.Ez = ez;
+}
+
+// RTUtils.py:102-108 GenerateDirectionSine
+template <typename real, bool TAPE>
+__device__ __forceinline__ void isotropic_direction(Photon<real> &p, Rng<real, TAPE> &g)
+{
+    real x, y, z;
+    g.event();
+    g.normal3(x, y, z);
+    normalize3(x, y, z);
+    p.Dx = x; p.Dy = y; p.Dz = z;
+}
+
+// PhotonObject.py:283-305 LamBeerDistance for an absorbing medium
+template <typename real>
+__device__ __forceinline__ real free_path(const DevAbs<real> &a, real e, real inv_scale)
+{
+    real b = a.b_a + a.b_d;
+    real mfp = b > real(0) ? M<real>::rcp(b) : M<real>::huge();
+    return inv_scale * (mfp * e);
+}
+
+// PhotonObject.py:49-97 ResetPhoton / GeneratePhoton
+template <typename real, bool TAPE>
+__device__ __forceinline__ void launch_photon(const DevScene<real> &sc, const Lds<real> &lds,
+                                              Photon<real> &p, Rng<real, TAPE> &g)
+{
+    const DevSource<real> &s = sc.src;
+    p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
+    if (s.dir_mode == 1) {
+        isotropic_direction(p, g);
+        real x = p.Dx, y = p.Dy, z = M<real>::abs(p.Dz);
+        p.Dx = x * s.frame[0] + y * s.frame[3] + z * s.frame[6];
+        p.Dy = x * s.frame[1] + y * s.frame[4] + z * s.frame[7];
+        p.Dz = x * s.frame[2] + y * s.frame[5] + z * s.frame[8];
+        normalize3(p.Dx, p.Dy, p.Dz);
+    } else {
+        p.Dx = s.dir[0]; p.Dy = s.dir[1]; p.Dz = s.dir[2];
+    }
+    if (s.wl_mode == 1) {
+        g.event();
+        p.wid = cdf_pick(lds.cdf + s.cdf_off, s.cdf_len, g.u32(0));
+    } else {
+        p.wid = s.wid_fixed;
+    }
+    p.wid0 = p.wid;
+    p.mat = s.start_mat;
+    random_polarization(p, g);
+    p.dist = real(0);
+    p.hitd = M<real>::inf();
+    p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+    p.last_el = -1;
+    p.s_old = 0;
+    p.status = RTMC_ST_START;
+    p.iter = 0;
+    p.was_el = false; p.reflected = false; p.absorbed_once = false;
+}
+
+// Geometries.py:32-52 Rectangle.FindIntersections for one element; returns the
+// line parameter t (B = L + t D) and whether B lies inside the rectangle.
+template <typename real>
+__device__ __forceinline__ bool rect_hit(const DevElem<real> &e, real Lx, real Ly, real Lz, real Dx,
+                                         real Dy, real Dz, real &t)
+{
+    real den = Dx * e.nx + Dy * e.ny + Dz * e.nz;
+    real num = e.d0 - (Lx * e.nx + Ly * e.ny + Lz * e.nz);
+    t = num * M<real>::rcp(den);
+    real Bx = Lx + t * Dx, By = Ly + t * Dy, Bz = Lz + t * Dz;
+    real t1 = Bx * e.ax + By * e.ay + Bz * e.az - e.c1;
+    real t2 = Bx * e.bx + By * e.by + Bz * e.bz - e.c2;
+    return (den != real(0)) & (M<real>::abs(t1) <= e.h1) & (M<real>::abs(t2) <= e.h2);
+}
+
+// Tally sinks -----------------------------------------------------------------
+// LdsTally: the trace kernel (workgroup accumulators in LDS, detector
+// histogram in HBM).  NoTally: the step-wise kernel.
+template <typename real>
+struct LdsTally {
+    unsigned long long *acc;
+    unsigned long long *hist;
+    const double *wl;
+    const uint32_t *eqeT;
+    int n_el, n_wid, n_src_lds;
+    __device__ __forceinline__ void scalar(int which, unsigned long long v = 1ull) { atomicAdd(&acc[which], v); }
+    __device__ __forceinline__ void bounce(int el) { atomicAdd(&acc[ACC_SCALARS + el], 1ull); }
+    // Elements.py:152-165 Dump tallies (Counter and the 1-nm spectrum are derived on the host from `hist`)
+    __device__ __forceinline__ void dump(int el, int wid, int wid0, bool counted)
+    {
+        if (wid < n_src_lds) atomicAdd(&acc[ACC_SCALARS + 3 * n_el + el * n_src_lds + wid], 1ull);
+        else atomicAdd(&hist[(size_t)el * n_wid + wid], 1ull);
+        double ratio = wl[wid0] / wl[wid];
+        atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], (unsigned long long)__double2ll_rn(ratio * RTMC_ENERGY_FX_SCALE));
+        if (counted) atomicAdd(&acc[ACC_SCALARS + n_el + el], 1ull);
+    }
+};
+struct NoTally {
+    __device__ __forceinline__ void scalar(int, unsigned long long = 1ull) {}
+    __device__ __forceinline__ void bounce(int) {}
+    __device__ __forceinline__ void dump(int, int, int, bool) {}
+};
+
+// MonteCarloFRET.py:63-193 RunSimulation, pathway choice and re-emission for
+// isotropic (non-aligned) dyes.  On entry the absorption event's block is
+// current; its word 0 was the donor/acceptor coin.
+template <typename real, bool TAPE>
+__device__ __forceinline__ void fret_event(const DevScene<real> &sc, const Lds<real> &lds,
+                                           const DevMat<real> &m, Photon<real> &p, Rng<real, TAPE> &g,
+                                           bool in_donor)
+{
+    bool have_block = true;
+    for (;;) {
+        if (!have_block) g.event();
+        have_block = false;
+        uint32_t v_lambda = TAPE ? 0u : g.u32(3);
+        // MonteCarloFRET.py:90: drawn also when the acceptor absorbed
+        uint32_t v = g.u32(1);
+        int pathway = (v >= m.pT[0]) + (v >= m.pT[1]);
+        if (pathway > m.n_p - 1) pathway = m.n_p - 1;
+        if (in_donor && pathway == 0) {  // :92-105 donor fluorescence
+            isotropic_direction(p, g);
+            if (TAPE) v_lambda = g.u32(3);
+            p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, v_lambda);
+            p.status = RTMC_ST_REEMITTED_DONOR;
+            random_polarization(p, g);
+            return;
+        }
+        if (in_donor && pathway == 1) {  // :106-109
+            p.status = RTMC_ST_INTERNAL_CONVERTED;
+            return;
+        }
+        if (m.n_p < 3) {  // no acceptor present: the reference has no acceptor pathways here
+            p.status = RTMC_ST_INTERNAL_CONVERTED;
+            return;
+        }
+        uint32_t va = g.u32(2);  // :119
+        int pa = (va >= m.pAT[0]) + (va >= m.pAT[1]);
+        if (pa == 0) {  // :170-175 acceptor fluorescence: direction, polarisation, wavelength
+            isotropic_direction(p, g);
+            random_polarization(p, g);
+            if (TAPE) v_lambda = g.u32(3);
+            p.wid = m.widA_off + cdf_pick(lds.cdf + m.cdfA_off, m.cdfA_len, v_lambda);
+            p.status = RTMC_ST_REEMITTED_ACCEPTOR;
+            return;
+        }
+        if (pa == 1) {  // :182-185
+            p.status = RTMC_ST_INTERNAL_CONVERTED;
+            return;
+        }
+        in_donor = true;  // :187-190 back transfer
+    }
+}
+
+// One iteration of the loop body, RayTrace.py:178-195.  Returns true while the
+// photon is still travelling.
+template <typename real, bool TAPE, typename Tally>
+__device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<real> &lds,
+                                            Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
+{
+    // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
+    // Candidates are ordered by |t| (the line parameter); the distance is
+    // |t| |D|.  A candidate is admissible if
+    //   - the photon last left an element: it lies on the side of that
+    //     element's plane the operation sent the photon to (RTUtils.CheckSides
+    //     against RayTrace.OldPoint; the photon itself is on the plane, so the
+    //     candidate's side is the sign of t * (n_last . D));
+    //   - otherwise (fresh emission): it is ahead, t > 0.
+    // The element the photon sits on is skipped by index; the reference
+    // rejects it through its 1e-8 distance test (RayTrace.py:134).
+    real nd_last = real(0);
+    bool want_same = false;
+    if (p.was_el && p.last_el >= 0) {
+        const DevElem<real> &le = lds.elems[p.last_el];
+        nd_last = le.nx * p.Dx + le.ny * p.Dy + le.nz * p.Dz;
+        // Elements.py:26-28 mirror: same side; :113-114 interface: same side iff reflected; :131-132 lens: other side
+        want_same = le.type == RTMC_TYPE_MIRROR ? true : (le.type == RTMC_TYPE_INTERFACE ? p.reflected : false);
+    }
+    real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+    real best = M<real>::inf(), best_t = real(0);
+    int best_e = -1;
+    const real eps_t = M<real>::self_hit_eps;
+    for (int e = 0; e < sc.n_el; e++) {
+        const DevElem<real> &el = sc.elems[e];  // wave-uniform address
+        real t;
+        bool ok = rect_hit(el, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
+        real at = M<real>::abs(t);
+        bool adm;
+        if (p.was_el) {
+            int side = sgn_i(t * nd_last);
+            adm = ((side == p.s_old) == want_same) & (e != p.last_el);
+        } else {
+            adm = t > real(0);
+        }
+        ok = ok & adm & (at < best) & (at * dnorm > eps_t);
+        best = ok ? at : best;
+        best_t = ok ? t : best_t;
+        best_e = ok ? e : best_e;
+    }
+    const bool stale = best_e < 0;
+    const int el_idx = stale ? p.last_el : best_e;
+    p.hitd = stale ? M<real>::inf() : best * dnorm;
+    p.last_el = el_idx;
+    if (stale) tally.scalar(ACC_STALE);
+    if (el_idx < 0) {  // nothing hit and no element visited before: the reference raises
+        p.status = RTMC_ST_LOST;
+        p.iter++;
+        return false;
+    }
+
+    // ---- PhotonObject.py:206-264 CheckForAbsorption -------------------------
+    const DevMat<real> &m = lds.mats[p.mat];
+    bool absorbed = false;
+    if (m.flags & 1) {
+        if (p.dist > p.hitd) {
+            p.dist -= p.hitd;
+            p.status = RTMC_ST_START;
+        } else {
+            absorbed = true;
+            p.absorbed_once = true;
+            p.was_el = false;
+            p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+            // move the rest of the free path towards the candidate point; with
+            // no candidate the reference aims at PointCy = (0,0,0)
+            real ux, uy, uz;
+            if (!stale) {
+                real s = (best_t < real(0) ? real(-1) : real(1)) * M<real>::rcp(dnorm);
+                ux = p.Dx * s; uy = p.Dy * s; uz = p.Dz * s;
+            } else {
+                ux = -p.Lx; uy = -p.Ly; uz = -p.Lz;
+                normalize3(ux, uy, uz);
+            }
+            p.Lx += ux * p.dist; p.Ly += uy * p.dist; p.Lz += uz * p.dist;
+            const DevAbs<real> &a = lds.abs[m.abs_slot * sc.lay.n_wid + p.wid];
+            g.event();
+            bool in_donor = g.u32(0) < a.coinT;  // PhotonObject.py:244
+            tally.scalar(ACC_ABSORPTIONS);
+            fret_event(sc, lds, m, p, g, in_donor);
+            if (p.status != RTMC_ST_INTERNAL_CONVERTED || g.consume_dead_draws()) {
+                g.event();
+                real e = g.expo(0);
+                p.dist = free_path(lds.abs[m.abs_slot * sc.lay.n_wid + p.wid], e, sc.src.inv_scale);
+            }
+        }
+    } else {
+        p.status = RTMC_ST_START;
+        p.was_el = true;
+    }
+
+    // ---- the element's ExecuteOperation -------------------------------------
+    if (!absorbed) {
+        const DevElem<real> &el = lds.elems[el_idx];  // per-lane gather from LDS
+        const real nx = el.nx, ny = el.ny, nz = el.nz;
+        const int type = el.type, info = el.info;
+        // PhotonObject.py:135-139 PrepareExecution
+        const real dn = p.Dx * nx + p.Dy * ny + p.Dz * nz;
+        const real off = p.Lx * nx + p.Ly * ny + p.Lz * nz - el.d0;  // signed distance of the segment start
+        const real sgn = real(sgn_i(-dn));
+        const real oDx = p.Dx, oDy = p.Dy, oDz = p.Dz;
+        p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+        // a stale re-execution starts on the plane itself: its old point has no side
+        p.s_old = stale ? 0 : sgn_i(off);
+        // every operation first moves the photon onto the plane
+        // (PhotonObject.py:149/198; Elements.py:167 for the detector)
+        if (type == RTMC_TYPE_DUMP && stale) {
+            p.Lx = p.Ly = p.Lz = real(0);
+        } else {
+            real t = -off * M<real>::rcp(dn);
+            p.Lx += t * p.Dx; p.Ly += t * p.Dy; p.Lz += t * p.Dz;
+        }
+        bool rotate = true;
+        if (type == RTMC_TYPE_DUMP) {  // Elements.py:152-169
+            p.status = RTMC_ST_DUMPED;
+            bool counted = true;
+            if (info > 0) {
+                g.event();
+                counted = g.u32(0) < sc.eqeT[(size_t)(info - 1) * sc.lay.n_wid + p.wid];
+            }
+            tally.dump(el_idx, p.wid, p.wid0, counted);
+            rotate = false;
+        } else {
+            bool reflect = true;
+            if (type == RTMC_TYPE_INTERFACE) {  // Elements.py:41-73
+                const int m1 = info & 0xFF, m2 = (info >> 8) & 0xFF;
+                const int other = (m.name_id == lds.mats[m1].name_id) ? m2 : m1;  // by name, Elements.py:45-48
+                const DevMat<real> &mo = lds.mats[other];
+                const real n1 = m.n, n2 = mo.n;
+                const real r = n1 * M<real>::rcp(n2);
+                const real c = M<real>::abs(dn);  // cos(theta_i) for unit D, as Elements.py:87 takes it
+                // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
+                const real cn = c * M<real>::rcp(dnorm);
+                const bool tir = (n1 > n2) & (cn * cn < real(1) - (n2 * n2) * M<real>::rcp(n1 * n1));
+                // the operation owns one draw event whether or not it needs variates
+                if (tir) g.skip(); else g.event();
+                if (!tir) {
+                    // Elements.py:84-109 Reflectance, with cos/sin taken algebraically
+                    real st2 = r * r * (real(1) - c * c);
+                    real ct = M<real>::sqrt(real(1) - st2);
+                    real a1 = n1 * c, a2 = n2 * ct, b1 = n2 * c, b2 = n1 * ct;
+                    real rs = (a1 - a2) * M<real>::rcp(a1 + a2);
+                    real rp = (b1 - b2) * M<real>::rcp(b1 + b2);
+                    real R_perp = rs * rs, R_par = rp * rp;
+                    normalize3(p.Ex, p.Ey, p.Ez);
+                    real kx = sgn * (p.Dy * nz - p.Dz * ny), ky = sgn * (p.Dz * nx - p.Dx * nz),
+                         kz = sgn * (p.Dx * ny - p.Dy * nx);
+                    real k2 = kx * kx + ky * ky + kz * kz;
+                    real R;
+                    if (k2 != real(0)) {
+                        real dp = (p.Ex * kx + p.Ey * ky + p.Ez * kz);
+                        real dp2 = dp * dp * M<real>::rcp(k2);
+                        R = (real(1) - dp2) * R_par + dp2 * R_perp;
+                    } else {
+                        real q = (n1 - n2) * M<real>::rcp(n1 + n2);
+                        R = q * q;
+                    }
+                    if (g.uniform(0) > R) {  // Elements.py:57-66 crossing
+                        reflect = false;
+                        // PhotonObject.py:199 Snell
+                        real cc = -dn;
+                        real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
+                        p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
+                        p.mat = other;
+                        p.reflected = false;
+                        if (mo.flags & 1)
+                            p.dist = free_path(lds.abs[mo.abs_slot * sc.lay.n_wid + p.wid], g.expo(1), sc.src.inv_scale);
+                        else
+                            p.dist = real(0);
+                    }
+                }
+                if (reflect) p.reflected = true;
+            }
+            if (reflect) {  // PhotonObject.py:150 (line-based: the negative of the mirror direction)
+                real c2 = real(2) * dn;
+                p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
+                tally.bounce(el_idx);
+            }
+        }
+        // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old)
+        if (rotate) {
+            real cx = p.Dy * oDz - p.Dz * oDy, cy = p.Dz * oDx - p.Dx * oDz, cz = p.Dx * oDy - p.Dy * oDx;
+            real c2n = cx * cx + cy * cy + cz * cz;
+            if (c2n != real(0)) {
+                real nn = p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz;
+                real iq = M<real>::rsqrt(nn * (dnorm * dnorm));  // 1 / (|D_new| |D_old|)
+                real c = (p.Dx * oDx + p.Dy * oDy + p.Dz * oDz) * iq;
+                if (c <= real(1) && c >= real(-1)) {
+                    real ce = cx * p.Ex + cy * p.Ey + cz * p.Ez;
+                    real coef = c >= real(0) ? iq * iq * M<real>::rcp(real(1) + c) : (real(1) - c) * M<real>::rcp(c2n);
+                    real xx = cy * p.Ez - cz * p.Ey, xy = cz * p.Ex - cx * p.Ez, xz = cx * p.Ey - cy * p.Ex;
+                    real ex = c * p.Ex - xx * iq + cx * (ce * coef);
+                    real ey = c * p.Ey - xy * iq + cy * (ce * coef);
+                    real ez = c * p.Ez - xz * iq + cz * (ce * coef);
+                    normalize3(ex, ey, ez);
+                    p.Ex = ex; p.Ey = ey; p.Ez = ez;
+                }
+            }
+        }
+        p.was_el = true;  // PhotonObject.py:143
+    }
+
+    // ---- RayTrace.py:193-195 ------------------------------------------------
+    bool stop = (p.status == RTMC_ST_INTERNAL_CONVERTED) | (p.status == RTMC_ST_DUMPED) |
+                (p.iter >= sc.max_iter - 1);
+    p.iter++;
+    return !stop;
+}
+
+// book-keeping when a photon has ended, RayTrace.py:197-199
+template <typename real, typename Tally>
+__device__ __forceinline__ void count_fate(const Photon<real> &p, Tally &tally)
+{
+    tally.scalar(ACC_PHOTONS);
+    tally.scalar(ACC_STEPS, (unsigned long long)p.iter);
+    if (p.absorbed_once) tally.scalar(ACC_ABS_ONCE);
+    int which = p.status == RTMC_ST_INTERNAL_CONVERTED ? ACC_IC
+              : p.status == RTMC_ST_DUMPED ? ACC_DUMPED
+              : p.status == RTMC_ST_LOST ? ACC_LOST : ACC_CAPPED;
+    tally.scalar(which);
+}
+#endif  // __HIPCC__
+
+}  // namespace rtmc

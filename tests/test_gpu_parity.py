@@ -1,0 +1,219 @@
+"""GPU parity tests: every call goes through the C ABI of librtmc.so.
+
+  * tape replays: the kernels consume the variates the reference drew
+    (tests/golden/trace_*.npz) and must reproduce its photons;
+  * single iterations started from the CPU checker's states: float32 outcomes
+    within 1e-6 (relative to the scene scale) of float64;
+  * Philox runs against the CPU checker driven by the same stream, and against
+    the reference's own seeded tallies within 3 sigma.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import _abi
+from raytracer_amd import scene as sc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            rt = H.raytrace_for(name)
+            cache[name] = (rt, rt.Scene())
+        return cache[name]
+    yield get
+    for rt, s in cache.values():
+        s.close()
+
+
+@pytest.mark.parametrize("name", H.TRACE_CONFIGS)
+def test_f64_tape_replay_matches_reference(scenes, name):
+    """float64 kernels + the reference's variates reproduce the reference's
+    photons iteration by iteration (discrete state exactly, vectors to 1e-9)."""
+    g = H.load_trace(name)
+    rt, s = scenes(name)
+    tr, batch = H.replay(s, g, precision=_abi.F64)
+    absorbers = [i for i, m in enumerate(s.packed.materials) if m.IsAbsorber]
+    worst, bad = H.compare_trace(g, tr, 1e-9, absorbers)
+    # the open slab's photons live on noise (stale re-executions decide by the
+    # sign of a rounding residue); a handful may leave the reference's path
+    allowed = 3 if name == "C1_open" else 0
+    assert len(bad) <= allowed, "photons off the reference path: %s (worst %.2e)" % (bad[:10], worst)
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+def test_f32_tape_replay_follows_reference(scenes, name):
+    """float32 kernels on the reference's variates: same discrete path for
+    (nearly) every photon and vectors within 2e-5 after a whole trajectory
+    (rounding accumulates over up to hundreds of iterations)."""
+    g = H.load_trace(name)
+    rt, s = scenes(name)
+    tr, batch = H.replay(s, g, precision=_abi.F32)
+    absorbers = [i for i, m in enumerate(s.packed.materials) if m.IsAbsorber]
+    worst, bad = H.compare_trace(g, tr, 2e-4, absorbers)
+    assert len(bad) <= max(1, len(g["n_iter"]) // 50), (bad[:10], worst)
+
+
+def _oracle_states(oracle_mod, rt, g, max_iter):
+    """Run the CPU checker one iteration at a time; return the list of batches."""
+    o = oracle_mod.OracleScene.from_raytrace(rt)
+    n = len(g["n_iter"])
+    batch = sc.new_photon_batch(n)
+    o.step_tape(batch, g["tape"], g["tape_off"], 0, launch=True)
+    states = [{k: v.copy() for k, v in batch.items()}]
+    for _ in range(max_iter):
+        o.step_tape(batch, g["tape"], g["tape_off"], 1, launch=False)
+        states.append({k: v.copy() for k, v in batch.items()})
+    return states
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
+    """One loop iteration from identical input state and identical variates:
+    float32 positions, directions, polarisation and free path agree with the
+    float64 checker within 1e-6 relative to the scene scale (5 cm), discrete
+    outcomes (element hit, reflect/refract, absorption pathway, wavelength)
+    identical, for every (photon, iteration) pair of the golden traces."""
+    g = H.load_trace(name)
+    rt, s = scenes(name)
+    iters = int(min(40, g["n_iter"].max()))
+    states = _oracle_states(oracle_mod, rt, g, iters)
+    n = len(g["n_iter"])
+    # stack all (iteration, photon) pairs that are still travelling into one batch
+    picks = [(i, k) for i in range(iters) for k in range(n)
+             if states[i]["status"][k] not in (4, 5, 6) and states[i]["iterations"][k] == i]
+    big = sc.new_photon_batch(len(picks))
+    off = np.zeros(len(picks) + 1, dtype=np.uint64)
+    tapes = []
+    for j, (i, k) in enumerate(picks):
+        for key, arr in states[i].items():
+            if arr.ndim == 2:
+                big[key][:, j] = arr[:, k]
+            else:
+                big[key][j] = arr[k]
+        seg = g["tape"][g["tape_off"][k]:g["tape_off"][k + 1]]
+        tapes.append(seg)
+        off[j + 1] = off[j] + len(seg)
+    tape = np.concatenate(tapes)
+    s.step_tape(big, tape, off, 1, launch=False, precision=_abi.F32)
+    scale = 5.0
+    bad_discrete = 0
+    worst = 0.0
+    for j, (i, k) in enumerate(picks):
+        ref = states[i + 1]
+        same = all(big[key][j] == ref[key][k] for key in
+                   ("status", "material", "last_element", "reflected", "tape_pos")) \
+            and big["wavelength"][j] == ref["wavelength"][k]
+        if not same:
+            bad_discrete += 1
+            continue
+        for key, denom in (("loc", scale), ("dir", 1.0), ("efield", 1.0)):
+            err = np.abs(big[key][:, j] - ref[key][:, k]).max() / denom
+            worst = max(worst, err)
+        in_abs = rt.Scene().packed.materials[int(ref["material"][k])].IsAbsorber
+        if in_abs and ref["dist_left"][k] < 1e30:
+            d = abs(big["dist_left"][j] - ref["dist_left"][k]) / max(scale, abs(ref["dist_left"][k]))
+            worst = max(worst, d)
+    assert bad_discrete <= max(1, len(picks) // 2000), (bad_discrete, len(picks))
+    assert worst < 1e-6, worst
+
+
+def test_rectangle_known_answers_on_gpu(golden_dir):
+    """Rectangle.FindIntersections on the constants of the reference's
+    TestGeometries.py and on random rectangles, through rtmc_op_intersect."""
+    from raytracer_amd import Geometries
+    from raytracer_amd.scene import intersect_single
+    k = np.load(golden_dir + "/kat.npz")
+    rect = Geometries.Rectangle(1.5, 2.5, [1.0, 2.0, 3.0], [0.0, 1.0, 0.0], None, [0, 0, 0])
+    assert np.isnan(intersect_single(rect, [0.0, -2.0, 2.0], [2.0, 2.0, 0.0])).all()
+    assert np.allclose(intersect_single(rect, [0.0, -2.0, 2.0], [0.2, 2.0, 0.1]), [0.4, 2.0, 2.2],
+                       atol=1e-14)
+    got32 = intersect_single(rect, [0.0, -2.0, 2.0], [0.2, 2.0, 0.1], precision=_abi.F32)
+    assert np.allclose(got32, [0.4, 2.0, 2.2], rtol=1e-6)
+    for i in range(0, len(k["rect_H"]), 8):
+        r = Geometries.Rectangle(k["rect_H"][i], k["rect_W"][i], k["rect_S"][i], k["rect_N"][i])
+        ref = k["rect_hit"][i]
+        got = intersect_single(r, k["rect_L"][i], k["rect_D"][i])
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        if not np.isnan(ref).any():
+            assert np.allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+def _sigma(n, p):
+    return max(1.0, (n * p * (1 - p)) ** 0.5)
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
+    """Same seed, same Philox stream, float64 on both sides: the integer
+    tallies agree except for photons that pass within rounding of an edge."""
+    rt, s = scenes(name)
+    n = 20000
+    gpu = s.run(n, seed=11, precision=_abi.F64)
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=11, threads=8)
+    for key in ("n_photons", "n_steps", "n_absorbed_once", "n_absorptions",
+                "n_internal_converted", "n_dumped", "n_capped", "n_lost"):
+        assert abs(int(gpu[key]) - int(cpu[key])) <= max(3, int(cpu[key]) // 2000), key
+    diff = np.abs(gpu["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()
+    assert diff <= 20, diff
+    assert gpu["n_photons"] == n and gpu["n_lost"] == 0
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C1_open"])
+def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
+    """Production path against the reference's own seeded runs
+    (tests/golden/ref_tallies.json): every detector count, internal
+    conversions and absorbed-once counts within 3 sigma binomial of the
+    reference sample (GPU sample 50x larger, so its own noise is small)."""
+    runs = H.ref_tallies(name)
+    if not runs:
+        pytest.skip("no reference tallies stored for %s" % name)
+    rt, s = scenes(name)
+    n_ref = sum(r["n"] for r in runs)
+    n_gpu = 2000000 if name != "C1_open" else 20000
+    gpu = s.run(n_gpu, seed=2024)
+    assert gpu["n_photons"] == n_gpu
+    ref_counter = np.sum([r["counter"] for r in runs], axis=0)
+    checks = [("element %d" % i, ref_counter[i], gpu["counter"][i]) for i in range(len(ref_counter))]
+    checks.append(("ic", sum(r["ic"] for r in runs), gpu["n_internal_converted"]))
+    checks.append(("absorbed_once", sum(r["absorbed_once"] for r in runs), gpu["n_absorbed_once"]))
+    checks.append(("capped", sum(r["capped"] for r in runs), gpu["n_capped"]))
+    for label, ref_count, gpu_count in checks:
+        p = float(gpu_count) / n_gpu
+        sig = _sigma(n_ref, p) * (1 + n_ref / n_gpu) ** 0.5
+        assert abs(ref_count - p * n_ref) <= 3 * sig + 1, (label, ref_count, p * n_ref, sig)
+    # optical efficiency = edge detectors / photons
+    edges = slice(2, 6)
+    eta_ref = ref_counter[edges].sum() / n_ref
+    eta_gpu = gpu["counter"][edges].sum() / n_gpu
+    assert abs(eta_ref - eta_gpu) <= 3 * _sigma(n_ref, eta_gpu) / n_ref * (1 + n_ref / n_gpu) ** 0.5
+
+
+def test_results_do_not_depend_on_batching(scenes):
+    """Photon ids key the variates: one call of 60000 ids equals three calls of 20000."""
+    rt, s = scenes("C3")
+    whole = s.run(60000, seed=5)
+    block = sc.new_tallies(s.n_elements)
+    for i in range(3):
+        s.run(20000, seed=5, first_photon=20000 * i, tallies=block)
+    parts = sc.tallies_to_dict(*block)
+    for key in ("counter", "spectral", "bounce", "energy_fx", "spectrum"):
+        assert np.array_equal(whole[key], parts[key]), key
+    for key in _abi.TALLY_SCALARS:
+        assert whole[key] == parts[key], key
+
+
+def test_empty_and_tiny_runs(scenes):
+    rt, s = scenes("C2")
+    t = s.run(0, seed=1)
+    assert t["n_photons"] == 0 and t["counter"].sum() == 0
+    t = s.run(1, seed=1)
+    assert t["n_photons"] == 1
+    t = s.run(65, seed=1)
+    assert t["n_photons"] == 65
+    assert t["n_dumped"] + t["n_internal_converted"] + t["n_capped"] + t["n_lost"] == 65
