@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the photon-transport hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one `rtmc_run` call: `--photons-per-step` photon ids of the
+benchmark scene traced on each rank's GPU (scene tables are resident in HBM
+before the timed region; the only output is the small tally block).  With
+N > 1 the ranks take disjoint id ranges and the integer tallies are summed
+once with an RCCL all-reduce inside the timed region.
+
+Workload (BASELINE.json configs[1]): the Lumogen Red slab "C2" -- 5 x 5 x 0.3 cm
+slab enclosed by a detector box, 460 nm source, 12 rectangles; K steps of
+2.5e8 photons by default, i.e. 1e9 photons per GPU for the default K = 4.
+
+Prints one JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X vector FP32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_iteration(n_elements):
+    """Algorithmic work of one loop iteration: 61 flop per element tested
+    (rectangle hit 35, distance 9, side test 17) + 250 for the optical
+    operation (Fresnel 105, reflect/refract 40, polarisation rotation 105)."""
+    return 61 * n_elements + 250
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--photons-per-step", type=float, default=2.5e8)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=float, default=2.0e7)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = local_rank
+
+    from raytracer_amd import RayTrace, configs, _abi, distributed
+    from raytracer_amd import scene as sc
+
+    per_step = int(args.photons_per_step)
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.make_job(args.config, per_step))
+    scene = rt.Scene()
+    n_el = scene.n_elements
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # every (rank, step) gets its own photon-id range
+    def first_id(step_index):
+        return (step_index * world + rank) * per_step
+
+    block = sc.new_tallies(n_el)
+    for w in range(args.warmup):
+        scene.run(per_step, seed=args.seed, first_photon=first_id(w), device=device,
+                  tallies=sc.new_tallies(n_el))
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        scene.run(per_step, seed=args.seed, first_photon=first_id(args.warmup + k), device=device,
+                  tallies=block)
+        kernel_ms.append(scene.last_kernel_ms(device))
+    distributed.allreduce_tallies(block, device)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tall = sc.tallies_to_dict(*block)
+
+    out = None
+    if rank == 0:
+        total_photons = per_step * args.steps * world
+        assert tall["n_photons"] == total_photons, (tall["n_photons"], total_photons)
+        iters_per_launch = tall["n_steps"] / (args.steps * world)
+        avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+        flops = iters_per_launch * flops_per_iteration(n_el)
+        achieved = flops / avg_kernel_s / 1e12
+        alg_bytes = per_step * 96.0     # one register-resident photon record per photon
+        edges = [2, 3, 4, 5]
+        out = {
+            "metric": "photons/sec",
+            "value": total_photons / elapsed,
+            "unit": "photons/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s: Lumogen Red slab 5x5x0.3 cm in a detector box, 460 nm "
+                                   "source, %d rectangles" % (args.config, n_el)
+                       if args.config == "C2" else args.config,
+                       "photons_per_step_per_gpu": per_step,
+                       "parallelism": "photon-id ranges, %d rank(s)" % world,
+                       "iterations_per_photon": tall["n_steps"] / tall["n_photons"],
+                       "optical_efficiency": float(tall["counter"][edges].sum()) / tall["n_photons"],
+                       "internal_converted": tall["n_internal_converted"] / tall["n_photons"],
+                       "capped": int(tall["n_capped"]), "lost": int(tall["n_lost"])},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "trace_kernel<float>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "flop_per_iteration": flops_per_iteration(n_el),
+                         "iterations_per_launch": iters_per_launch,
+                         "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "frac": alg_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS,
+                                 "algorithmic_bytes_per_photon": 96}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(rt, int(args.cpu_sample), args.seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(rt, sample, seed):
+    """The float64 CPU checker (oracle/) on a bounded sample of the same workload."""
+    from oracle import oracle
+    threads = min(16, os.cpu_count() or 1)
+    o = oracle.OracleScene.from_raytrace(rt)
+    t0 = time.perf_counter()
+    r = o.run_threads(sample, seed=seed, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "photons/s", "cores": threads, "kind": "port",
+            "sample": "%d photons of the same scene, float64 scalar C restatement of the "
+                      "reference loop, %d host threads, %.1f s" % (sample, threads, dt),
+            "optical_efficiency": float(r["counter"][[2, 3, 4, 5]].sum()) / r["n_photons"]}
+
+
+if __name__ == "__main__":
+    main()
