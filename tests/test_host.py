@@ -1,0 +1,173 @@
+"""Host-side logic: job files, materials, scene packing, ABI surface.  No GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import (Elements, Geometries, IOOperation, Materials, RayTrace, RTUtils,
+                           _abi, configs, distributed, prt)
+from raytracer_amd import scene as sc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/rtmc.h declares is exported by librtmc.so (load only, no compute)."""
+    header = open(os.path.join(REPO, "include", "rtmc.h")).read()
+    declared = set(re.findall(r"\b(rtmc_[a-z_0-9]+)\s*\(", header))
+    declared -= {"rtmc_scene"}
+    assert declared == set(_abi.EXPORTS)
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.rtmc_version.restype = ctypes.c_int
+    assert lib.rtmc_version() == _abi.ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors have the C layout (compiled probe with the real header)."""
+    import subprocess
+    import tempfile
+    src = r'''
+    #include <stdio.h>
+    #include "rtmc.h"
+    int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(rtmc_element), sizeof(rtmc_table),
+        sizeof(rtmc_material), sizeof(rtmc_source), sizeof(rtmc_scene_desc), sizeof(rtmc_tallies),
+        sizeof(rtmc_photon_soa)); return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "p.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), "-o", os.path.join(d, "p"),
+                               os.path.join(d, "p.c")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "p")]).split()]
+    mine = [ctypes.sizeof(t) for t in (_abi.Element, _abi.Table, _abi.Material, _abi.Source,
+                                       _abi.SceneDesc, _abi.Tallies, _abi.PhotonSoA)]
+    assert sizes == mine
+
+
+def test_scene_create_validates_without_gpu():
+    """rtmc_scene_create is host-only: bad descriptions are refused with a message."""
+    lib = _abi.load_library()
+    rt = H.raytrace_for("C2")
+    packed = sc.PackedScene(rt.OpticalElements, rt.Photon, rt.MaterialDict)
+    h = ctypes.c_void_p()
+    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == 0
+    cnt = ctypes.c_int64()
+    assert lib.rtmc_scene_wavelengths(h, ctypes.byref(cnt), None, 0) == 0
+    assert cnt.value == 1 + 481 + 1200
+    lib.rtmc_scene_destroy(h)
+    packed.desc.abi_version = 99
+    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == -1
+    assert b"ABI version" in lib.rtmc_last_error()
+    packed.desc.abi_version = _abi.ABI_VERSION
+    packed.el_array[0].geometry = 3
+    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == -2
+    assert b"rectangles" in lib.rtmc_last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(_abi.RtmcError):
+        _abi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_prt_reader_on_the_shipped_job_layout(tmp_path):
+    """The protocol-0 subset reader/writer round-trips a job, including a numpy
+    array written the way the reference's GUI pickles `Elements`."""
+    job = configs.make_job("C1_open", 1000)
+    prt.dump_job(str(tmp_path), job)
+    back = prt.load_job(str(tmp_path))
+    assert np.array_equal(np.array(back["Elements"]), job["Elements"])
+    for k in ("ElementProperties", "ElementGeometry", "ElementSize", "Materials", "Photon"):
+        assert back[k] == job[k]
+    # a Python-2 style pickle of an ndarray (protocol 0, numpy reconstruct opcodes)
+    arr = np.arange(12, dtype="<f8").reshape(2, 2, 3) / 7.0
+    raw = arr.tobytes()
+    esc = "".join("\\x%02x" % b for b in raw)
+    text = ("cnumpy.core.multiarray\n_reconstruct\np1\n(cnumpy\nndarray\np2\n(I0\ntS'b'\ntRp3\n"
+            "(I1\n(L2L\nL2L\nL3L\ntcnumpy\ndtype\np4\n(S'f8'\nI0\nI1\ntRp5\n(I3\nS'<'\nNNNI-1\nI-1\nI0\n"
+            "tbI00\nS'" + esc + "'\ntb.")
+    got = prt.loads(text.encode("latin1"))
+    assert np.array_equal(got, arr)
+
+
+def test_prt_reader_refuses_code():
+    evil = b"cos\nsystem\n(S'echo pwned'\ntR."
+    with pytest.raises(prt.PrtError):
+        prt.loads(evil)
+    with pytest.raises(prt.PrtError):
+        prt.loads(b"\x80\x02]q\x00.")      # binary protocols are outside the subset
+
+
+def test_parse_path_and_savelog_formats(tmp_path):
+    """ParsePath on a job folder rebuilds the scene; SaveLog writes the
+    reference's result files (IOOperation.py:34-69) with its layouts."""
+    job = configs.make_job("C3", 123)
+    folder = str(tmp_path / "job")
+    prt.dump_job(folder, job)
+    rt = RayTrace.RayTrace()
+    assert len(rt.OpticalElements) == 17          # the constructor's demo scene
+    rt.IOOperator.ParsePath(folder)
+    assert rt.NumberOfPhotons == 123 and len(rt.OpticalElements) == 12
+    assert isinstance(rt.OpticalElements[0].Type, Elements.Interface)
+    assert rt.OpticalElements[0].Type.MaterialSide1 is rt.MaterialDict["LRO"]
+    assert isinstance(rt.OpticalElements[2].Type, Elements.Dump)
+    assert rt.Photon.StartingMaterial is rt.MaterialDict["air"]
+    # publish fake tallies and write the log
+    t = sc.tallies_to_dict(*sc.new_tallies(12))
+    t["counter"][2] = 5; t["spectral"][2] = 5; t["energy_fx"][2] = 3 << 24
+    t["energy"] = t["energy_fx"].astype(float) / _abi.ENERGY_FX_SCALE
+    t["spectrum"][2, 410] = 5; t["bounce"][0] = 7; t["n_absorbed_once"] = 4
+    rt._publish(t)
+    out = rt.IOOperator.SaveLog()
+    log = np.loadtxt(os.path.join(out, "Logfile.txt"))
+    assert log.shape == (12, 4)
+    assert list(log[2]) == [5, 3, 5, 0] and log[0, 3] == 7
+    spec = np.loadtxt(os.path.join(out, "DetectorSpectrum2.txt"))
+    assert spec.shape == (3800, 2) and spec[0, 0] == 200 and spec[410, 1] == 5
+    assert np.loadtxt(os.path.join(out, "AbsorbedPhotons.txt")) == 4
+    again = prt.load_job(out)
+    assert again["ElementProperties"][0] == [2, "LRO", "air"]
+
+
+def test_rectangle_axes_follow_reference_rules():
+    k = np.load(os.path.join(H.GOLDEN, "kat.npz"))
+    for i in range(len(k["rect_H"])):
+        r = Geometries.Rectangle(k["rect_H"][i], k["rect_W"][i], k["rect_S"][i], k["rect_N"][i])
+        assert np.allclose(r.DirectionVector, k["rect_n"][i], atol=1e-15)
+        assert np.allclose(r.e1, k["rect_e1"][i], atol=1e-15)
+        assert np.allclose(r.e2, k["rect_e2"][i], atol=1e-15)
+    # axis-aligned special cases of the shipped slab
+    r = Geometries.Rectangle(2.5, 2.5, [0, 0, 0], [0, 0, 1.0])
+    assert np.array_equal(np.abs(r.e1), [1, 0, 0]) and np.array_equal(np.abs(r.e2), [0, 1, 0])
+    r = Geometries.Rectangle(2.5, 0.006, [2.5, 0, 0.006], [-1.0, 0, 0])
+    assert np.array_equal(np.abs(r.e1), [0, 1, 0]) and np.array_equal(np.abs(r.e2), [0, 0, 1])
+
+
+def test_rtutils_against_reference_vectors():
+    k = np.load(os.path.join(H.GOLDEN, "kat.npz"))
+    assert np.array_equal(RTUtils.FindClosestListElement(k["fc_A"], k["fc_T"]), k["fc_idx"])
+    for d, tm in zip(k["frame_dirs"], k["frame_tm"]):
+        assert np.allclose(RTUtils.z_axis_frame(d), tm, atol=1e-15)
+    m = np.load(os.path.join(H.GOLDEN, "materials.npz"))
+    rt = H.raytrace_for("C3")
+    mat = rt.MaterialDict["LRO"]
+    assert np.allclose(RTUtils.RectifySpectrum(mat.sp_em_A), m["C3_LRO_rect_em_A"], rtol=1e-14, atol=0)
+
+
+def test_shard_range_covers_ids_once():
+    for n in (0, 1, 7, 1000, 10**9 + 3):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                first, cnt = distributed.shard_range(n, r, world)
+                assert first == nxt
+                nxt += cnt
+            assert nxt == n
+
+
+def test_synthetic_sun_table():
+    t = configs.synthetic_am15()
+    assert t.shape == (801, 2) and t[0, 0] == 300 and t[-1, 0] == 1100
+    assert t[:, 1].max() == 1.0 and 480 < t[np.argmax(t[:, 1]), 0] < 520
