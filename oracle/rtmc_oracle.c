@@ -362,7 +362,6 @@ typedef struct {
 static void polarization_random(ph_t *p, rng_t *g, const double *dir)
 {
     double v[3];
-    rng_event(g);
     rng_normal3(g, v);
     double n = norm3(v);
     v[0] /= n; v[1] /= n; v[2] /= n;
@@ -374,10 +373,32 @@ static void polarization_random(ph_t *p, rng_t *g, const double *dir)
 /* RTUtils.py:102-108 GenerateDirectionSine */
 static void direction_isotropic(rng_t *g, double *d)
 {
-    rng_event(g);
     rng_normal3(g, d);
     double n = norm3(d);
     d[0] /= n; d[1] /= n; d[2] /= n;
+}
+
+/* Philox mode only: exact samplers of the same laws from uniforms, written
+ * like the HIP kernels write them (csrc/rtmc_device.h sphere_direction,
+ * perpendicular) so that both follow the same photons. */
+static void sphere_direction(double u_z, double u_phi, double *d)
+{
+    const double two_pi = 6.283185307179586;
+    double z = 1.0 - 2.0 * u_z;
+    double r2 = 1.0 - z * z;
+    double r = sqrt(r2 > 0 ? r2 : 0.0);
+    d[0] = r * cos(two_pi * u_phi); d[1] = r * sin(two_pi * u_phi); d[2] = z;
+}
+static void perpendicular(const double *D, double u_psi, double *E)
+{
+    const double two_pi = 6.283185307179586;
+    double sg = copysign(1.0, D[2]);
+    double a = -1.0 / (sg + D[2]);
+    double b = D[0] * D[1] * a;
+    double s = sin(two_pi * u_psi), c = cos(two_pi * u_psi);
+    E[0] = c * (1.0 + sg * D[0] * D[0] * a) + s * b;
+    E[1] = c * (sg * b) + s * (sg + D[1] * D[1] * a);
+    E[2] = c * (-sg * D[0]) + s * (-D[1]);
 }
 
 /* PhotonObject.py:283-305 LamBeerDistance (non-aligned) */
@@ -401,9 +422,11 @@ static void launch_photon(const orc_scene *s, ph_t *p, rng_t *g)
     const rtmc_source *src = &s->src;
     p->was_element = 0;
     memcpy(p->L, src->location, sizeof p->L);
+    rng_event(g); /* philox: one event for the whole launch: words 0,1 direction, 2 polarisation, 3 wavelength */
     if (src->direction_mode == 1) {
         double d[3];
-        direction_isotropic(g, d);
+        if (g->tape_mode) direction_isotropic(g, d);
+        else sphere_direction(u24(g->w[0]), u24(g->w[1]), d);
         d[2] = fabs(d[2]);
         for (int j = 0; j < 3; j++) /* row vector times matrix */
             p->D[j] = fma(d[2], src->frame[6 + j], fma(d[1], src->frame[3 + j], d[0] * src->frame[j]));
@@ -411,13 +434,13 @@ static void launch_photon(const orc_scene *s, ph_t *p, rng_t *g)
         memcpy(p->D, src->direction, sizeof p->D);
     double n = norm3(p->D);
     p->D[0] /= n; p->D[1] /= n; p->D[2] /= n;
-    if (src->wavelength_mode == 1) {
-        rng_event(g);
-        p->wl = s->sun.x[cdf_pick(s->sun_cdf, s->sun.len, rng_uniform(g, 0))];
-    } else
+    if (src->wavelength_mode == 1)
+        p->wl = s->sun.x[cdf_pick(s->sun_cdf, s->sun.len, rng_uniform(g, 3))];
+    else
         p->wl = src->wavelength;
     p->mat = src->start_material;
-    polarization_random(p, g, p->D);
+    if (g->tape_mode) polarization_random(p, g, p->D);
+    else perpendicular(p->D, u24(g->w[2]), p->E);
     p->wl0 = p->wl;
     p->reflected = 0;
     if (s->n_el > 0) {
@@ -511,6 +534,14 @@ static double emit_wavelength(const omat_t *M, int donor, double u)
     return M->em_A.x[cdf_pick(M->cdf_A, M->em_A.len, u)];
 }
 
+/* philox mode: the re-emission event, words 0,1 direction, 2 polarisation, 3 free path */
+static void emit_philox(ph_t *p, rng_t *g)
+{
+    rng_event(g);
+    sphere_direction(u24(g->w[0]), u24(g->w[1]), p->D);
+    perpendicular(p->D, u24(g->w[2]), p->E);
+}
+
 /* MonteCarloFRET.py:63-193 RunSimulation (non-aligned acceptor).  `have_block`:
  * the caller has already opened the draw event (its word 0 was the
  * donor/acceptor coin). */
@@ -526,11 +557,14 @@ static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int 
         int pathway = (int)cdf_pick(M->cdf_p, M->n_p, rng_uniform(g, 1));
         if (pathway == 0 && in_donor) {
             /* MonteCarloFRET.py:92-105: direction, wavelength, polarisation */
-            direction_isotropic(g, p->D);
-            if (g->tape_mode) u_lambda = tape_next(g);
+            if (g->tape_mode) {
+                direction_isotropic(g, p->D);
+                u_lambda = tape_next(g);
+                polarization_random(p, g, p->D);
+            } else
+                emit_philox(p, g);
             p->wl = emit_wavelength(M, 1, u_lambda);
             p->status = RTMC_ST_REEMITTED_DONOR;
-            polarization_random(p, g, p->D);
             return;
         }
         if (pathway == 1 && in_donor) { /* :106-109 */
@@ -541,9 +575,12 @@ static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int 
         int pa = (int)cdf_pick(M->cdf_pA, 3, rng_uniform(g, 2));
         if (pa == 0) {
             /* :170-175 direction, polarisation, wavelength */
-            direction_isotropic(g, p->D);
-            polarization_random(p, g, p->D);
-            if (g->tape_mode) u_lambda = tape_next(g);
+            if (g->tape_mode) {
+                direction_isotropic(g, p->D);
+                polarization_random(p, g, p->D);
+                u_lambda = tape_next(g);
+            } else
+                emit_philox(p, g);
             p->wl = emit_wavelength(M, 0, u_lambda);
             p->status = RTMC_ST_REEMITTED_ACCEPTOR;
             return;
@@ -582,10 +619,8 @@ static void check_absorption(const orc_scene *s, ph_t *p, rng_t *g, const double
             fret_event(s, p, g, in_donor, 1);
             p->absorbed_now = 1;
             /* PhotonObject.py:250/258: a new free path is drawn whatever happened */
-            if (g->tape_mode || p->status != RTMC_ST_INTERNAL_CONVERTED) {
-                rng_event(g);
-                lambeer_distance(s, p, g, 0);
-            }
+            if (g->tape_mode || p->status != RTMC_ST_INTERNAL_CONVERTED)
+                lambeer_distance(s, p, g, 3);
         }
     } else {
         p->status = RTMC_ST_START;

@@ -54,8 +54,13 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 }
 
 // Traces photon ids [first, first + n).  Every wave draws blocks of ids from
-// `work` and refills lanes whose photon has ended; the grid is sized to the
-// machine, not to n.
+// `work`; a lane whose photon has ended or has been absorbed goes through the
+// *renew* block (new id + launch, or pathway choice + re-emission) before it
+// takes part in the next loop iteration.  Launch and re-emission share one
+// Philox event and one pass through the direction / polarisation samplers.
+// The grid is sized to the machine, not to n.
+enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
+
 template <typename real>
 __global__ void __launch_bounds__(TRACE_BLOCK)
 trace_kernel(DevScene<real> sc, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
@@ -66,51 +71,93 @@ trace_kernel(DevScene<real> sc, DevTallies tl, uint64_t seed, uint64_t first, ui
     Lds<real> lds = stage_lds(sc, smem, n_acc);
 
     LdsTally<real> tally;
-    tally.acc = lds.acc; tally.hist = tl.hist; tally.wl = sc.wl; tally.eqeT = sc.eqeT;
+    tally.acc = lds.acc; tally.hist = tl.hist; tally.wl = sc.wl; tally.energy_fx = sc.energy_fx;
+    tally.eqeT = sc.eqeT;
     tally.n_el = sc.n_el; tally.n_wid = (int)sc.lay.n_wid; tally.n_src_lds = (int)sc.lay.n_src_lds;
+    tally.fixed_source = sc.src.wl_mode == 0;
 
     Photon<real> p;
     Rng<real, false> g;
     g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32);
     g.id0 = g.id1 = g.ev = 0;
-    bool alive = false;
+    int need = NEED_LAUNCH;
     uint64_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;
     const uint32_t lane = threadIdx.x & 63;
 
     for (;;) {
-        const unsigned long long idle = __ballot(!alive);
-        if (idle != 0ull && !exhausted) {
-            if (chunk_next == chunk_end) {
-                unsigned long long s = 0;
-                if (lane == 0) s = atomicAdd(work, (unsigned long long)WORK_CHUNK);
-                uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)s);
-                uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
-                s = ((unsigned long long)hi << 32) | lo;
-                if (s >= n) exhausted = true;
-                else { chunk_next = s; chunk_end = (s + WORK_CHUNK < n) ? s + WORK_CHUNK : n; }
-            }
-            if (!exhausted) {
-                const uint32_t avail = (uint32_t)(chunk_end - chunk_next);
-                const uint32_t rank = lanes_below(idle);
-                if (!alive && rank < avail) {
-                    const uint64_t id = first + chunk_next + rank;
-                    g.id0 = (uint32_t)id; g.id1 = (uint32_t)(id >> 32); g.ev = 0;
-                    launch_photon(sc, lds, p, g);
-                    alive = true;
+        if (__ballot(need == NEED_LAUNCH || need == NEED_EMIT) != 0ull) {
+            // (a) absorbed photons: donor/acceptor coin and pathway (PhotonObject.py:244,
+            //     MonteCarloFRET.py:63-193); one event, a back transfer opens another
+            bool emitting = false;
+            if (need == NEED_EMIT) {
+                const DevMat<real> &m = lds.mats[p.mat];
+                const DevAbs<real> &a = lds.abs[m.abs_slot * sc.lay.n_wid + p.wid];
+                g.event();
+                const bool in_donor = g.u32(0) < a.coinT;
+                uint32_t v_lambda;
+                const int outcome = fret_decide(m, g, in_donor, v_lambda);
+                if (outcome == 1) {
+                    p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, v_lambda);
+                    p.status = RTMC_ST_REEMITTED_DONOR;
+                } else if (outcome == 2) {
+                    p.wid = m.widA_off + cdf_pick(lds.cdf + m.cdfA_off, m.cdfA_len, v_lambda);
+                    p.status = RTMC_ST_REEMITTED_ACCEPTOR;
+                } else {
+                    p.status = RTMC_ST_INTERNAL_CONVERTED;
                 }
-                const uint32_t want = (uint32_t)__popcll(idle);
-                chunk_next += want < avail ? want : avail;
+                if (finish_absorbed_iteration(sc, p) == STEP_ENDED) {
+                    count_fate(p, tally);
+                    need = NEED_LAUNCH;
+                } else {
+                    emitting = true;
+                }
+            }
+            // (b) photon ids for the lanes without a photon
+            bool launching = false;
+            const unsigned long long idle = __ballot(need == NEED_LAUNCH);
+            if (idle != 0ull && !exhausted) {
+                if (chunk_next == chunk_end) {
+                    unsigned long long s = 0;
+                    if (lane == 0) s = atomicAdd(work, (unsigned long long)WORK_CHUNK);
+                    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)s);
+                    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(s >> 32));
+                    s = ((unsigned long long)hi << 32) | lo;
+                    if (s >= n) exhausted = true;
+                    else { chunk_next = s; chunk_end = (s + WORK_CHUNK < n) ? s + WORK_CHUNK : n; }
+                }
+                if (!exhausted) {
+                    const uint32_t avail = (uint32_t)(chunk_end - chunk_next);
+                    const uint32_t rank = lanes_below(idle);
+                    if (need == NEED_LAUNCH && rank < avail) {
+                        const uint64_t id = first + chunk_next + rank;
+                        g.id0 = (uint32_t)id; g.id1 = (uint32_t)(id >> 32); g.ev = 0;
+                        launching = true;
+                    }
+                    const uint32_t want = (uint32_t)__popcll(idle);
+                    chunk_next += want < avail ? want : avail;
+                }
+            }
+            if (exhausted && need == NEED_LAUNCH) need = NEED_OFF;
+            // (c) one event for both: direction, polarisation, free path / wavelength
+            if (launching | emitting) {
+                g.event();
+                if (launching) renew_launch(sc, lds, p, g);
+                else renew_emit(sc, lds, lds.mats[p.mat], p, g);
+                need = NEED_NONE;
             }
         }
-        if (__ballot(alive) == 0ull) {
-            if (exhausted) break;
+        if (__ballot(need == NEED_NONE) == 0ull) {
+            if (__ballot(need != NEED_OFF) == 0ull) break;
             continue;
         }
-        if (alive) {
-            if (!photon_step(sc, lds, p, g, tally)) {
+        if (need == NEED_NONE) {
+            const StepResult r = photon_step(sc, lds, p, g, tally);
+            if (r == STEP_ENDED) {
                 count_fate(p, tally);
-                alive = false;
+                need = NEED_LAUNCH;
+            } else if (r == STEP_ABSORBED) {
+                need = NEED_EMIT;
             }
         }
     }
@@ -157,7 +204,7 @@ step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int 
     g.overrun = false;
     Photon<real> p;
     if (launch) {
-        launch_photon(sc, lds, p, g);
+        launch_in_reference_order(sc, lds, p, g);
     } else {
         p.Lx = real(b.loc[0][k]); p.Ly = real(b.loc[1][k]); p.Lz = real(b.loc[2][k]);
         p.Dx = real(b.dir[0][k]); p.Dy = real(b.dir[1][k]); p.Dz = real(b.dir[2][k]);
@@ -170,19 +217,25 @@ step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int 
         p.was_el = b.was_element[k] != 0; p.reflected = b.reflected[k] != 0;
         p.iter = b.iterations[k];
         p.absorbed_once = false;
-        p.s_old = 0;
-        if (p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
+        p.best_t = real(0);
+        set_admissibility_forward(p);
+        if (p.was_el && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
             const DevElem<real> &le = lds.elems[p.last_el];
             double s = (double)le.nx * b.old_point[0][k] + (double)le.ny * b.old_point[1][k] +
                        (double)le.nz * b.old_point[2][k] - (double)le.d0;
-            p.s_old = (s > 0) - (s < 0);
+            set_admissibility(p, le.type, (s > 0) - (s < 0), le.nx * p.Dx + le.ny * p.Dy + le.nz * p.Dz);
         }
     }
     NoTally tally;
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
                    p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
     for (uint32_t it = 0; it < n_steps && alive; it++) {
-        alive = photon_step(sc, lds, p, g, tally);
+        StepResult r = photon_step(sc, lds, p, g, tally);
+        if (r == STEP_ABSORBED) {
+            emit_in_reference_order(sc, lds, p, g);
+            r = finish_absorbed_iteration(sc, p);
+        }
+        alive = r == STEP_CONTINUE;
         if (trace) {
             double *r = trace + ((size_t)k * n_steps + it) * RTMC_TRACE_STRIDE;
             r[0] = p.Lx; r[1] = p.Ly; r[2] = p.Lz; r[3] = p.Dx; r[4] = p.Dy; r[5] = p.Dz;
@@ -298,6 +351,7 @@ uint32_t threshold32(double q)
 template <typename real>
 struct DeviceImage {
     std::vector<DevElem<real>> elems;
+    std::vector<HitRec<real>> hits;
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
     DevSource<real> src;
@@ -308,6 +362,8 @@ struct PerDevice {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *elems32 = nullptr, *elems64 = nullptr, *lds32 = nullptr, *lds64 = nullptr;
+    void *hits32 = nullptr, *hits64 = nullptr;
+    unsigned long long *energy_fx = nullptr;
     double *wl = nullptr;
     uint32_t *eqeT = nullptr;
     unsigned long long *tallies = nullptr;  // scalars | bounce | spectral | energy | hist
@@ -324,6 +380,7 @@ struct rtmc_scene {
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
+    std::vector<unsigned long long> energy_fx;  // fixed-wavelength source: energy increment per id
     std::vector<int32_t> wid_bin;   // detector spectrum bin of each wavelength id
     std::vector<int32_t> el_eqe;    // per element: eqe table or -1
     DeviceImage<float> img32;
@@ -360,6 +417,32 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.info = 0;
         if (e.type == RTMC_TYPE_INTERFACE) o.info = e.material1 | (e.material2 << 8);
         if (e.type == RTMC_TYPE_DUMP) o.info = e.eqe_table + 1;
+    }
+    // axis-aligned rectangles get the short hit test
+    img.hits.resize(n_el);
+    for (int i = 0; i < n_el; i++) {
+        const rtmc_element &e = d->elements[i];
+        HitRec<real> &h = img.hits[i];
+        memset(&h, 0, sizeof h);
+        h.kind = 3;
+        auto axis_of = [](const double *v) {  // index of the only non-zero component if it is +-1
+            int k = -1;
+            for (int j = 0; j < 3; j++) {
+                if (v[j] == 0.0) continue;
+                if (k >= 0 || std::fabs(v[j]) != 1.0) return -1;
+                k = j;
+            }
+            return k;
+        };
+        const int kn = axis_of(e.normal), k1 = axis_of(e.e1), k2 = axis_of(e.e2);
+        if (kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2) {
+            const int ai = (kn + 1) % 3, aj = (kn + 2) % 3;
+            h.kind = kn;
+            h.p0 = (real)e.support[kn];
+            h.ci = (real)e.support[ai]; h.cj = (real)e.support[aj];
+            h.hi = (real)(k1 == ai ? e.half1 : e.half2);
+            h.hj = (real)(k1 == ai ? e.half2 : e.half1);
+        }
     }
     std::vector<DevMat<real>> mats(n_mat);
     int n_slots = 0;
@@ -563,6 +646,11 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     for (int i = 0; i < RTMC_SPECTRUM_BINS; i++) bins[i] = RTMC_SPECTRUM_FIRST_NM + i;
     s->wid_bin.resize(wl.size());
     for (size_t w = 0; w < wl.size(); w++) s->wid_bin[w] = (int32_t)nearest_index(bins, wl[w]);
+    // Elements.py:158 EnergyCounter += wl_start / wl, in units of 2^-24, for a single source line
+    s->energy_fx.assign(wl.size(), 0ull);
+    if (src.wavelength_mode == 0)
+        for (size_t w = 0; w < wl.size(); w++)
+            s->energy_fx[w] = (unsigned long long)std::llrint(wl[0] / wl[w] * RTMC_ENERGY_FX_SCALE);
     // detection thresholds, Elements.py:164
     s->eqeT.assign(std::max<size_t>(1, (size_t)d->n_tables * wl.size()), 0xFFFFFFFFu);
     for (int t = 0; t < d->n_tables; t++) {
@@ -586,7 +674,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
 static void free_device(PerDevice &p)
 {
     if (!p.ready) return;
-    void *bufs[] = {p.elems32, p.elems64, p.lds32, p.lds64, p.wl, p.eqeT, p.tallies, p.work};
+    void *bufs[] = {p.elems32, p.elems64, p.lds32, p.lds64, p.hits32, p.hits64, p.energy_fx,
+                    p.wl, p.eqeT, p.tallies, p.work};
     for (void *b : bufs) (void)hipFree(b);
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
@@ -635,6 +724,9 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
     };
     HIP_TRY(upload(&p.elems32, s->img32.elems.data(), sizeof(DevElem<float>) * s->n_el));
     HIP_TRY(upload(&p.elems64, s->img64.elems.data(), sizeof(DevElem<double>) * s->n_el));
+    HIP_TRY(upload(&p.hits32, s->img32.hits.data(), sizeof(HitRec<float>) * s->n_el));
+    HIP_TRY(upload(&p.hits64, s->img64.hits.data(), sizeof(HitRec<double>) * s->n_el));
+    HIP_TRY(upload((void **)&p.energy_fx, s->energy_fx.data(), 8 * s->energy_fx.size()));
     HIP_TRY(upload(&p.lds32, s->img32.lds.data(), s->img32.lds.size()));
     HIP_TRY(upload(&p.lds64, s->img64.lds.data(), s->img64.lds.size()));
     HIP_TRY(upload((void **)&p.wl, s->wl.data(), sizeof(double) * s->wl.size()));
@@ -661,6 +753,8 @@ template <typename real>
 static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, const DeviceImage<real> &img)
 {
     DevScene<real> sc;
+    sc.hits = (const HitRec<real> *)(sizeof(real) == 4 ? p.hits32 : p.hits64);
+    sc.energy_fx = p.energy_fx;
     sc.elems = (const DevElem<real> *)(sizeof(real) == 4 ? p.elems32 : p.elems64);
     sc.lds_image = (const uint32_t *)(sizeof(real) == 4 ? p.lds32 : p.lds64);
     sc.wl = p.wl;
@@ -724,7 +818,7 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     const unsigned long long *sc = host.data();
     const unsigned long long *bounce = sc + ACC_SCALARS, *spectral = bounce + s->n_el,
                              *energy = spectral + s->n_el, *hist = energy + s->n_el;
-    out->n_photons += sc[ACC_PHOTONS];
+    out->n_photons += sc[ACC_IC] + sc[ACC_DUMPED] + sc[ACC_CAPPED] + sc[ACC_LOST];
     out->n_steps += sc[ACC_STEPS];
     out->n_absorbed_once += sc[ACC_ABS_ONCE];
     out->n_absorptions += sc[ACC_ABSORPTIONS];

@@ -5,14 +5,16 @@
 // photon has ended (ballot + prefix count).  Everything a photon looks up is
 // staged in LDS at kernel start: the element records used by the optical
 // operations, the media, and per wavelength-id the absorption coefficients and
-// inverse-CDF thresholds.  The element records used by the nearest-hit search
-// are read with wave-uniform indices so that they travel through the scalar
-// cache into SGPRs.
+// inverse-CDF thresholds.  The records used by the nearest-hit search are read
+// with wave-uniform indices so that they travel through the scalar cache into
+// SGPRs.
 //
 // The code is a template over the arithmetic type: `float` is the production
 // instantiation, `double` exists to validate the logic against the float64
-// CPU checker.  It is also a template over the source of variates: Philox
-// (production) or a tape of recorded values (parity tests).
+// CPU checker.  Variates come either from Philox (production; its launch and
+// re-emission code is the `renew_*` family) or from a tape of recorded values
+// consumed in the reference's order (parity tests; `launch_in_reference_order`
+// and `emit_in_reference_order`).  Both share the loop iteration `photon_step`.
 //
 // Reference file:line citations name the statement of mohrezaeib/RayTracer
 // that a routine stands for.
@@ -29,7 +31,7 @@ namespace rtmc {
 // records shared between host (scene builder) and device
 // ---------------------------------------------------------------------------
 
-// One element as the nearest-hit search and the optical operation see it.
+// One element as the optical operation sees it (and the general hit test).
 // plane: n.x = d0; in-plane coordinates t1 = a.x - c1, t2 = b.x - c2.
 template <typename real>
 struct DevElem {
@@ -39,6 +41,17 @@ struct DevElem {
     real h1, h2;
     int32_t type;  // RTMC_TYPE_*
     int32_t info;  // interface: material1 | material2 << 8; dump: eqe table + 1
+};
+
+// The same element as the nearest-hit search sees it.  kind 0/1/2: the normal
+// is the x/y/z axis and the in-plane axes are the other two (i = kind+1,
+// j = kind+2 cyclically): plane coordinate p0, centre (ci, cj), half extents
+// (hi, hj).  kind 3: general orientation, use DevElem.
+template <typename real>
+struct HitRec {
+    real p0, ci, cj, hi, hj;
+    int32_t kind;
+    int32_t pad[sizeof(real) == 4 ? 2 : 5];
 };
 
 // One medium.
@@ -89,9 +102,11 @@ enum { ACC_STEPS = 0, ACC_ABS_ONCE, ACC_ABSORPTIONS, ACC_IC, ACC_DUMPED, ACC_CAP
 
 template <typename real>
 struct DevScene {
-    const DevElem<real> *elems;  // global copy for wave-uniform reads
+    const HitRec<real> *hits;    // global, wave-uniform reads
+    const DevElem<real> *elems;  // global copy for wave-uniform reads (general elements)
     const uint32_t *lds_image;   // elems | mats | abs | cdf, copied to LDS by every workgroup
     const double *wl;            // wavelength of each id
+    const unsigned long long *energy_fx;  // fixed wavelength source: llrint(wl0 / wl[id] * 2^24) per id
     const uint32_t *eqeT;        // [n_eqe][n_wid] detection thresholds
     DevSource<real> src;
     LdsLayout lay;
@@ -118,8 +133,10 @@ template <> struct M<float> {
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float log(float x) { return ::logf(x); }
     static __device__ __forceinline__ void sincospi(float x, float *s, float *c) { ::sincospif(x, s, c); }
+    static __device__ __forceinline__ float copysign(float m, float s) { return __builtin_copysignf(m, s); }
     static __device__ __forceinline__ float huge() { return 3.0e38f; }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+    static constexpr bool has_self_hit_eps = false;
     static constexpr float self_hit_eps = 0.0f;
 };
 template <> struct M<double> {
@@ -129,8 +146,10 @@ template <> struct M<double> {
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ void sincospi(double x, double *s, double *c) { ::sincospi(x, s, c); }
+    static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
     static __device__ __forceinline__ double huge() { return 1.0e300; }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+    static constexpr bool has_self_hit_eps = true;
     static constexpr double self_hit_eps = 1e-8;  // RayTrace.py:134
 };
 
@@ -156,7 +175,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 // A draw *event* is one place of the photon's life where variates are needed
-// (launch polarisation, one interface operation, one absorption, ...).  In
+// (launch, one interface operation, one absorption, one re-emission, ...).  In
 // Philox mode every event owns one counter value, i.e. four fresh 32-bit
 // words; a word is used as a 24-bit uniform k/2^24.  In tape mode the values
 // are read sequentially in the order the reference draws them.
@@ -174,16 +193,7 @@ struct Rng<real, false> {
     __device__ __forceinline__ real uniform(int slot) { return real(w[slot] >> 8) * real(1.0 / 16777216.0); }
     // unit exponential, numpy legacy form -log(1 - U)
     __device__ __forceinline__ real expo(int slot) { return -M<real>::log(real(1) - uniform(slot)); }
-    __device__ __forceinline__ void normal3(real &a, real &b, real &c)
-    {
-        real r0 = M<real>::sqrt(real(-2) * M<real>::log((real(w[0] >> 8) + real(1)) * real(1.0 / 16777216.0)));
-        real r1 = M<real>::sqrt(real(-2) * M<real>::log((real(w[2] >> 8) + real(1)) * real(1.0 / 16777216.0)));
-        real s0, c0, s1, c1;
-        M<real>::sincospi(real(2) * uniform(1), &s0, &c0);
-        M<real>::sincospi(real(2) * uniform(3), &s1, &c1);
-        a = r0 * c0; b = r0 * s0; c = r1 * c1;
-        (void)s1;
-    }
+    __device__ __forceinline__ void normal3(real &a, real &b, real &c) { a = b = c = real(0); }
     __device__ __forceinline__ bool consume_dead_draws() const { return false; }
 };
 
@@ -223,14 +233,17 @@ struct Photon {
     real Lx, Ly, Lz, Dx, Dy, Dz, Ex, Ey, Ez;
     real dist;       // DistanceLeftToAbsorption
     real hitd;       // SmallestDistance of the last iteration
-    real oldx, oldy, oldz;  // RayTrace.OldPoint (kept for the step-wise interface only)
+    real best_t;     // signed line parameter of the last candidate
+    real oldx, oldy, oldz;  // RayTrace.OldPoint (read back by the step-wise interface only)
+    // Admissibility of the next candidate at line parameter t (see photon_step):
+    // (t * adm_q > 0) or adm_all.
+    real adm_q;
     int32_t wid, wid0;
     int32_t mat;
     int32_t last_el;  // RayTrace.FirstEl, -1 none
-    int32_t s_old;    // side of RayTrace.OldPoint w.r.t. the last operation plane: -1, 0, +1
     int32_t status;
     int32_t iter;
-    bool was_el, reflected, absorbed_once;
+    bool adm_all, was_el, reflected, absorbed_once;
 };
 
 // Views into the LDS image.
@@ -261,12 +274,67 @@ __device__ __forceinline__ void normalize3(real &x, real &y, real &z)
     x *= s; y *= s; z *= s;
 }
 
+// PhotonObject.py:283-305 LamBeerDistance for an absorbing medium
+template <typename real>
+__device__ __forceinline__ real free_path(const DevAbs<real> &a, real e, real inv_scale)
+{
+    real b = a.b_a + a.b_d;
+    real mfp = b > real(0) ? M<real>::rcp(b) : M<real>::huge();
+    return inv_scale * (mfp * e);
+}
+
+// What the next nearest-hit search may accept, from the operation just
+// executed.  `side` is the side (-1, 0, +1) of the segment's start point
+// (RayTrace.OldPoint) relative to the operation plane, `nd` = n . D_new.
+//   Elements.py:26-28   mirror:    candidate on the same side as the old point
+//   Elements.py:113-114 interface: same side iff the photon was reflected
+//   Elements.py:131-132 lens:      other side
+// A candidate at parameter t lies on side sign(t * nd) (the photon itself is on
+// the plane).  side == 0 happens when an operation is re-executed in place
+// (nothing was found, RayTrace.py:124-154): then no candidate is "on the same
+// side" and every candidate is "on another side".
+template <typename real>
+__device__ __forceinline__ void set_admissibility(Photon<real> &p, int type, int side, real nd)
+{
+    const bool want_same = type == RTMC_TYPE_MIRROR ? true : (type == RTMC_TYPE_INTERFACE ? p.reflected : false);
+    p.adm_all = (side == 0) & !want_same;
+    p.adm_q = side == 0 ? real(0) : (want_same ? nd * real(side) : -nd * real(side));
+}
+
+// A photon that does not come from an element (launch, re-emission) accepts
+// what lies ahead: t > 0 (RayTrace.py:143-150).
+template <typename real>
+__device__ __forceinline__ void set_admissibility_forward(Photon<real> &p)
+{
+    p.adm_all = false;
+    p.adm_q = real(1);
+}
+
+template <typename real>
+__device__ __forceinline__ void init_photon_common(const DevScene<real> &sc, Photon<real> &p)
+{
+    p.wid0 = p.wid;
+    p.mat = sc.src.start_mat;
+    p.dist = real(0);
+    p.hitd = M<real>::inf();
+    p.best_t = real(0);
+    p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+    p.last_el = -1;
+    p.status = RTMC_ST_START;
+    p.iter = 0;
+    p.was_el = false; p.reflected = false; p.absorbed_once = false;
+    set_admissibility_forward(p);
+}
+
+// ---------------------------------------------------------------------------
+// launch and re-emission, reference order of draws (tape mode)
+// ---------------------------------------------------------------------------
+
 // PhotonObject.py:107-114 UpdatePolarizationRandom: E = unit(D x unit(v)), v ~ N(0,1)^3
 template <typename real, bool TAPE>
 __device__ __forceinline__ void random_polarization(Photon<real> &p, Rng<real, TAPE> &g)
 {
     real vx, vy, vz;
-    g.event();
     g.normal3(vx, vy, vz);
     normalize3(vx, vy, vz);
     real ex = p.Dy * vz - p.Dz * vy, ey = p.Dz * vx - p.Dx * vz, ez = p.Dx * vy - p.Dy * vx;
@@ -279,59 +347,166 @@ template <typename real, bool TAPE>
 __device__ __forceinline__ void isotropic_direction(Photon<real> &p, Rng<real, TAPE> &g)
 {
     real x, y, z;
-    g.event();
     g.normal3(x, y, z);
     normalize3(x, y, z);
     p.Dx = x; p.Dy = y; p.Dz = z;
 }
 
-// PhotonObject.py:283-305 LamBeerDistance for an absorbing medium
 template <typename real>
-__device__ __forceinline__ real free_path(const DevAbs<real> &a, real e, real inv_scale)
+__device__ __forceinline__ void apply_source_frame(const DevSource<real> &s, Photon<real> &p)
 {
-    real b = a.b_a + a.b_d;
-    real mfp = b > real(0) ? M<real>::rcp(b) : M<real>::huge();
-    return inv_scale * (mfp * e);
+    real x = p.Dx, y = p.Dy, z = M<real>::abs(p.Dz);  // PhotonObject.py:70-72
+    p.Dx = x * s.frame[0] + y * s.frame[3] + z * s.frame[6];
+    p.Dy = x * s.frame[1] + y * s.frame[4] + z * s.frame[7];
+    p.Dz = x * s.frame[2] + y * s.frame[5] + z * s.frame[8];
+    normalize3(p.Dx, p.Dy, p.Dz);
 }
 
 // PhotonObject.py:49-97 ResetPhoton / GeneratePhoton
-template <typename real, bool TAPE>
-__device__ __forceinline__ void launch_photon(const DevScene<real> &sc, const Lds<real> &lds,
-                                              Photon<real> &p, Rng<real, TAPE> &g)
+template <typename real>
+__device__ __forceinline__ void launch_in_reference_order(const DevScene<real> &sc, const Lds<real> &lds,
+                                                          Photon<real> &p, Rng<real, true> &g)
 {
     const DevSource<real> &s = sc.src;
     p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
     if (s.dir_mode == 1) {
         isotropic_direction(p, g);
-        real x = p.Dx, y = p.Dy, z = M<real>::abs(p.Dz);
-        p.Dx = x * s.frame[0] + y * s.frame[3] + z * s.frame[6];
-        p.Dy = x * s.frame[1] + y * s.frame[4] + z * s.frame[7];
-        p.Dz = x * s.frame[2] + y * s.frame[5] + z * s.frame[8];
-        normalize3(p.Dx, p.Dy, p.Dz);
+        apply_source_frame(s, p);
     } else {
         p.Dx = s.dir[0]; p.Dy = s.dir[1]; p.Dz = s.dir[2];
     }
-    if (s.wl_mode == 1) {
-        g.event();
-        p.wid = cdf_pick(lds.cdf + s.cdf_off, s.cdf_len, g.u32(0));
-    } else {
-        p.wid = s.wid_fixed;
-    }
-    p.wid0 = p.wid;
-    p.mat = s.start_mat;
+    p.wid = s.wl_mode == 1 ? cdf_pick(lds.cdf + s.cdf_off, s.cdf_len, g.u32(0)) : s.wid_fixed;
     random_polarization(p, g);
-    p.dist = real(0);
-    p.hitd = M<real>::inf();
-    p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
-    p.last_el = -1;
-    p.s_old = 0;
-    p.status = RTMC_ST_START;
-    p.iter = 0;
-    p.was_el = false; p.reflected = false; p.absorbed_once = false;
+    init_photon_common(sc, p);
 }
 
-// Geometries.py:32-52 Rectangle.FindIntersections for one element; returns the
-// line parameter t (B = L + t D) and whether B lies inside the rectangle.
+// MonteCarloFRET.py:63-193 RunSimulation, pathway choice for isotropic
+// (non-aligned) dyes.  Word use of the absorption event's block: 0 coin
+// (already consumed), 1 donor pathway, 2 acceptor pathway, 3 wavelength; a
+// back transfer opens a new event.  Returns 0: internal conversion,
+// 1: donor fluoresces, 2: acceptor fluoresces; `v_lambda` is the wavelength
+// uniform in Philox mode (in tape mode it is drawn later, in reference order).
+template <typename real, bool TAPE>
+__device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE> &g, bool in_donor,
+                                           uint32_t &v_lambda)
+{
+    bool have_block = true;
+    for (;;) {
+        if (!have_block) g.event();
+        have_block = false;
+        v_lambda = TAPE ? 0u : g.u32(3);
+        // MonteCarloFRET.py:90: drawn also when the acceptor absorbed
+        uint32_t v = g.u32(1);
+        int pathway = (v >= m.pT[0]) + (v >= m.pT[1]);
+        if (pathway > m.n_p - 1) pathway = m.n_p - 1;
+        if (in_donor && pathway == 0) return 1;  // :92-105
+        if (in_donor && pathway == 1) return 0;  // :106-109
+        if (m.n_p < 3) return 0;  // no acceptor present: the reference has no acceptor pathways here
+        uint32_t va = g.u32(2);  // :119
+        int pa = (va >= m.pAT[0]) + (va >= m.pAT[1]);
+        if (pa == 0) return 2;   // :170-175
+        if (pa == 1) return 0;   // :182-185
+        in_donor = true;         // :187-190 back transfer
+    }
+}
+
+// PhotonObject.py:219-258 after the photon has been moved to the absorption
+// point: donor/acceptor coin, pathway, re-emission, new free path -- with the
+// draws in the reference's order.
+template <typename real>
+__device__ __forceinline__ void emit_in_reference_order(const DevScene<real> &sc, const Lds<real> &lds,
+                                                        Photon<real> &p, Rng<real, true> &g)
+{
+    const DevMat<real> &m = lds.mats[p.mat];
+    const DevAbs<real> &a = lds.abs[m.abs_slot * sc.lay.n_wid + p.wid];
+    bool in_donor = g.u32(0) < a.coinT;  // PhotonObject.py:244
+    uint32_t v_lambda;
+    int outcome = fret_decide(m, g, in_donor, v_lambda);
+    if (outcome == 1) {  // direction, wavelength, polarisation (MonteCarloFRET.py:95-103)
+        isotropic_direction(p, g);
+        p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, g.u32(3));
+        p.status = RTMC_ST_REEMITTED_DONOR;
+        random_polarization(p, g);
+    } else if (outcome == 2) {  // direction, polarisation, wavelength (MonteCarloFRET.py:172-175)
+        isotropic_direction(p, g);
+        random_polarization(p, g);
+        p.wid = m.widA_off + cdf_pick(lds.cdf + m.cdfA_off, m.cdfA_len, g.u32(3));
+        p.status = RTMC_ST_REEMITTED_ACCEPTOR;
+    } else {
+        p.status = RTMC_ST_INTERNAL_CONVERTED;
+    }
+    // PhotonObject.py:250/258: a free path is drawn whatever happened
+    p.dist = free_path(lds.abs[m.abs_slot * sc.lay.n_wid + p.wid], g.expo(0), sc.src.inv_scale);
+}
+
+// ---------------------------------------------------------------------------
+// launch and re-emission, Philox mode
+// ---------------------------------------------------------------------------
+// Uniform direction on the sphere from two uniforms.  The reference normalises
+// three normals (RTUtils.py:102-108); both are exact samplers of the same law.
+template <typename real>
+__device__ __forceinline__ void sphere_direction(real u_z, real u_phi, real &x, real &y, real &z)
+{
+    z = real(1) - real(2) * u_z;
+    real r2 = real(1) - z * z;
+    real r = M<real>::sqrt(r2 > real(0) ? r2 : real(0));
+    real s, c;
+    M<real>::sincospi(real(2) * u_phi, &s, &c);
+    x = r * c; y = r * s;
+}
+
+// Uniform unit vector perpendicular to the unit vector D.  The reference
+// normalises D x v for an isotropic v (PhotonObject.py:107-114), which is the
+// same law.  Orthonormal basis after Duff et al. (2017).
+template <typename real>
+__device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_psi, real &Ex, real &Ey, real &Ez)
+{
+    real sg = M<real>::copysign(real(1), Dz);
+    real a = real(-1) * M<real>::rcp(sg + Dz);
+    real b = Dx * Dy * a;
+    real s, c;
+    M<real>::sincospi(real(2) * u_psi, &s, &c);
+    Ex = c * (real(1) + sg * Dx * Dx * a) + s * b;
+    Ey = c * (sg * b) + s * (sg + Dy * Dy * a);
+    Ez = c * (-sg * Dx) + s * (-Dy);
+}
+
+// Launch (PhotonObject.py:49-97) with one event: words 0,1 direction (hemisphere
+// source only), 2 polarisation angle, 3 wavelength (spectrum source only).
+template <typename real>
+__device__ __forceinline__ void renew_launch(const DevScene<real> &sc, const Lds<real> &lds, Photon<real> &p,
+                                             Rng<real, false> &g)
+{
+    const DevSource<real> &s = sc.src;
+    p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
+    if (s.dir_mode == 1) {
+        sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
+        apply_source_frame(s, p);
+    } else {
+        p.Dx = s.dir[0]; p.Dy = s.dir[1]; p.Dz = s.dir[2];
+    }
+    p.wid = s.wl_mode == 1 ? cdf_pick(lds.cdf + s.cdf_off, s.cdf_len, g.u32(3)) : s.wid_fixed;
+    perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
+    init_photon_common(sc, p);
+}
+
+// Re-emission (MonteCarloFRET.py:92-105,170-175 + PhotonObject.py:250/258)
+// with one event: words 0,1 direction, 2 polarisation angle, 3 free path.
+template <typename real>
+__device__ __forceinline__ void renew_emit(const DevScene<real> &sc, const Lds<real> &lds, const DevMat<real> &m,
+                                           Photon<real> &p, Rng<real, false> &g)
+{
+    sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
+    perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
+    p.dist = free_path(lds.abs[m.abs_slot * sc.lay.n_wid + p.wid], g.expo(3), sc.src.inv_scale);
+}
+
+// ---------------------------------------------------------------------------
+// nearest valid hit
+// ---------------------------------------------------------------------------
+// Geometries.py:32-52 Rectangle.FindIntersections for one element of general
+// orientation; returns the line parameter t (B = L + t D) and whether B lies
+// inside the rectangle.
 template <typename real>
 __device__ __forceinline__ bool rect_hit(const DevElem<real> &e, real Lx, real Ly, real Lz, real Dx,
                                          real Dy, real Dz, real &t)
@@ -345,6 +520,19 @@ __device__ __forceinline__ bool rect_hit(const DevElem<real> &e, real Lx, real L
     return (den != real(0)) & (M<real>::abs(t1) <= e.h1) & (M<real>::abs(t2) <= e.h2);
 }
 
+// The same test for a rectangle whose normal is coordinate axis k:
+// t = (p0 - L_k) / D_k = p0 * (1/D_k) + (-L_k / D_k); the caller passes the two
+// per-iteration constants of its axis and the other two coordinate pairs.
+// D_k == 0 makes t infinite or NaN and both comparisons false.
+template <typename real>
+__device__ __forceinline__ bool axis_hit(const HitRec<real> &r, real inv_dk, real m_lk, real Li, real Di,
+                                         real Lj, real Dj, real &t)
+{
+    t = r.p0 * inv_dk + m_lk;
+    real Bi = Li + t * Di, Bj = Lj + t * Dj;
+    return (M<real>::abs(Bi - r.ci) <= r.hi) & (M<real>::abs(Bj - r.cj) <= r.hj);
+}
+
 // Tally sinks -----------------------------------------------------------------
 // LdsTally: the trace kernel (workgroup accumulators in LDS, detector
 // histogram in HBM).  NoTally: the step-wise kernel.
@@ -353,8 +541,10 @@ struct LdsTally {
     unsigned long long *acc;
     unsigned long long *hist;
     const double *wl;
+    const unsigned long long *energy_fx;
     const uint32_t *eqeT;
     int n_el, n_wid, n_src_lds;
+    bool fixed_source;
     __device__ __forceinline__ void scalar(int which, unsigned long long v = 1ull) { atomicAdd(&acc[which], v); }
     __device__ __forceinline__ void bounce(int el) { atomicAdd(&acc[ACC_SCALARS + el], 1ull); }
     // Elements.py:152-165 Dump tallies (Counter and the 1-nm spectrum are derived on the host from `hist`)
@@ -362,8 +552,10 @@ struct LdsTally {
     {
         if (wid < n_src_lds) atomicAdd(&acc[ACC_SCALARS + 3 * n_el + el * n_src_lds + wid], 1ull);
         else atomicAdd(&hist[(size_t)el * n_wid + wid], 1ull);
-        double ratio = wl[wid0] / wl[wid];
-        atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], (unsigned long long)__double2ll_rn(ratio * RTMC_ENERGY_FX_SCALE));
+        unsigned long long fx = fixed_source
+            ? energy_fx[wid]
+            : (unsigned long long)__double2ll_rn(wl[wid0] / wl[wid] * RTMC_ENERGY_FX_SCALE);
+        atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], fx);
         if (counted) atomicAdd(&acc[ACC_SCALARS + n_el + el], 1ull);
     }
 };
@@ -373,124 +565,65 @@ struct NoTally {
     __device__ __forceinline__ void dump(int, int, int, bool) {}
 };
 
-// MonteCarloFRET.py:63-193 RunSimulation, pathway choice and re-emission for
-// isotropic (non-aligned) dyes.  On entry the absorption event's block is
-// current; its word 0 was the donor/acceptor coin.
-template <typename real, bool TAPE>
-__device__ __forceinline__ void fret_event(const DevScene<real> &sc, const Lds<real> &lds,
-                                           const DevMat<real> &m, Photon<real> &p, Rng<real, TAPE> &g,
-                                           bool in_donor)
-{
-    bool have_block = true;
-    for (;;) {
-        if (!have_block) g.event();
-        have_block = false;
-        uint32_t v_lambda = TAPE ? 0u : g.u32(3);
-        // MonteCarloFRET.py:90: drawn also when the acceptor absorbed
-        uint32_t v = g.u32(1);
-        int pathway = (v >= m.pT[0]) + (v >= m.pT[1]);
-        if (pathway > m.n_p - 1) pathway = m.n_p - 1;
-        if (in_donor && pathway == 0) {  // :92-105 donor fluorescence
-            isotropic_direction(p, g);
-            if (TAPE) v_lambda = g.u32(3);
-            p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, v_lambda);
-            p.status = RTMC_ST_REEMITTED_DONOR;
-            random_polarization(p, g);
-            return;
-        }
-        if (in_donor && pathway == 1) {  // :106-109
-            p.status = RTMC_ST_INTERNAL_CONVERTED;
-            return;
-        }
-        if (m.n_p < 3) {  // no acceptor present: the reference has no acceptor pathways here
-            p.status = RTMC_ST_INTERNAL_CONVERTED;
-            return;
-        }
-        uint32_t va = g.u32(2);  // :119
-        int pa = (va >= m.pAT[0]) + (va >= m.pAT[1]);
-        if (pa == 0) {  // :170-175 acceptor fluorescence: direction, polarisation, wavelength
-            isotropic_direction(p, g);
-            random_polarization(p, g);
-            if (TAPE) v_lambda = g.u32(3);
-            p.wid = m.widA_off + cdf_pick(lds.cdf + m.cdfA_off, m.cdfA_len, v_lambda);
-            p.status = RTMC_ST_REEMITTED_ACCEPTOR;
-            return;
-        }
-        if (pa == 1) {  // :182-185
-            p.status = RTMC_ST_INTERNAL_CONVERTED;
-            return;
-        }
-        in_donor = true;  // :187-190 back transfer
-    }
-}
+enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 
-// One iteration of the loop body, RayTrace.py:178-195.  Returns true while the
-// photon is still travelling.
+// One iteration of the loop body, RayTrace.py:178-195, up to the point where an
+// absorbed photon needs its pathway drawn: the caller does that
+// (emit_in_reference_order / the renew block of the trace kernel) and then
+// calls finish_absorbed_iteration.
 template <typename real, bool TAPE, typename Tally>
-__device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<real> &lds,
-                                            Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
+__device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, const Lds<real> &lds,
+                                                  Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
 {
     // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
     // Candidates are ordered by |t| (the line parameter); the distance is
-    // |t| |D|.  A candidate is admissible if
-    //   - the photon last left an element: it lies on the side of that
-    //     element's plane the operation sent the photon to (RTUtils.CheckSides
-    //     against RayTrace.OldPoint; the photon itself is on the plane, so the
-    //     candidate's side is the sign of t * (n_last . D));
-    //   - otherwise (fresh emission): it is ahead, t > 0.
-    // The element the photon sits on is skipped by index; the reference
-    // rejects it through its 1e-8 distance test (RayTrace.py:134).
-    real nd_last = real(0);
-    bool want_same = false;
-    if (p.was_el && p.last_el >= 0) {
-        const DevElem<real> &le = lds.elems[p.last_el];
-        nd_last = le.nx * p.Dx + le.ny * p.Dy + le.nz * p.Dz;
-        // Elements.py:26-28 mirror: same side; :113-114 interface: same side iff reflected; :131-132 lens: other side
-        want_same = le.type == RTMC_TYPE_MIRROR ? true : (le.type == RTMC_TYPE_INTERFACE ? p.reflected : false);
-    }
-    real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
-    real best = M<real>::inf(), best_t = real(0);
+    // |t| |D|.  Admissibility: see set_admissibility.  The element the photon
+    // sits on is skipped by index; the reference rejects it through its 1e-8
+    // distance test (RayTrace.py:134), which the float64 instantiation keeps.
+    const real inv_x = M<real>::rcp(p.Dx), inv_y = M<real>::rcp(p.Dy), inv_z = M<real>::rcp(p.Dz);
+    const real m_x = -p.Lx * inv_x, m_y = -p.Ly * inv_y, m_z = -p.Lz * inv_z;
+    const real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+    const int skip = p.was_el ? p.last_el : -1;
+    real best_t = M<real>::inf();
     int best_e = -1;
-    const real eps_t = M<real>::self_hit_eps;
     for (int e = 0; e < sc.n_el; e++) {
-        const DevElem<real> &el = sc.elems[e];  // wave-uniform address
+        const HitRec<real> &r = sc.hits[e];  // wave-uniform address
         real t;
-        bool ok = rect_hit(el, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
-        real at = M<real>::abs(t);
-        bool adm;
-        if (p.was_el) {
-            int side = sgn_i(t * nd_last);
-            adm = ((side == p.s_old) == want_same) & (e != p.last_el);
-        } else {
-            adm = t > real(0);
+        bool ok;
+        switch (r.kind) {  // wave-uniform branch
+        case 0: ok = axis_hit(r, inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, t); break;
+        case 1: ok = axis_hit(r, inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, t); break;
+        case 2: ok = axis_hit(r, inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, t); break;
+        default: ok = rect_hit(sc.elems[e], p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t); break;
         }
-        ok = ok & adm & (at < best) & (at * dnorm > eps_t);
-        best = ok ? at : best;
+        const bool adm = (t * p.adm_q > real(0)) | p.adm_all;
+        ok = ok & adm & (e != skip) & (M<real>::abs(t) < M<real>::abs(best_t));
+        if (M<real>::has_self_hit_eps) ok = ok & (M<real>::abs(t) * dnorm > M<real>::self_hit_eps);
         best_t = ok ? t : best_t;
         best_e = ok ? e : best_e;
     }
     const bool stale = best_e < 0;
     const int el_idx = stale ? p.last_el : best_e;
-    p.hitd = stale ? M<real>::inf() : best * dnorm;
+    p.hitd = stale ? M<real>::inf() : M<real>::abs(best_t) * dnorm;
+    p.best_t = best_t;
     p.last_el = el_idx;
     if (stale) tally.scalar(ACC_STALE);
     if (el_idx < 0) {  // nothing hit and no element visited before: the reference raises
         p.status = RTMC_ST_LOST;
         p.iter++;
-        return false;
+        return STEP_ENDED;
     }
 
     // ---- PhotonObject.py:206-264 CheckForAbsorption -------------------------
     const DevMat<real> &m = lds.mats[p.mat];
-    bool absorbed = false;
     if (m.flags & 1) {
         if (p.dist > p.hitd) {
             p.dist -= p.hitd;
             p.status = RTMC_ST_START;
         } else {
-            absorbed = true;
             p.absorbed_once = true;
             p.was_el = false;
+            p.status = RTMC_ST_ABSORBED;
             p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
             // move the rest of the free path towards the candidate point; with
             // no candidate the reference aims at PointCy = (0,0,0)
@@ -503,16 +636,9 @@ __device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<
                 normalize3(ux, uy, uz);
             }
             p.Lx += ux * p.dist; p.Ly += uy * p.dist; p.Lz += uz * p.dist;
-            const DevAbs<real> &a = lds.abs[m.abs_slot * sc.lay.n_wid + p.wid];
-            g.event();
-            bool in_donor = g.u32(0) < a.coinT;  // PhotonObject.py:244
+            set_admissibility_forward(p);
             tally.scalar(ACC_ABSORPTIONS);
-            fret_event(sc, lds, m, p, g, in_donor);
-            if (p.status != RTMC_ST_INTERNAL_CONVERTED || g.consume_dead_draws()) {
-                g.event();
-                real e = g.expo(0);
-                p.dist = free_path(lds.abs[m.abs_slot * sc.lay.n_wid + p.wid], e, sc.src.inv_scale);
-            }
+            return STEP_ABSORBED;
         }
     } else {
         p.status = RTMC_ST_START;
@@ -520,7 +646,7 @@ __device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<
     }
 
     // ---- the element's ExecuteOperation -------------------------------------
-    if (!absorbed) {
+    {
         const DevElem<real> &el = lds.elems[el_idx];  // per-lane gather from LDS
         const real nx = el.nx, ny = el.ny, nz = el.nz;
         const int type = el.type, info = el.info;
@@ -531,7 +657,7 @@ __device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<
         const real oDx = p.Dx, oDy = p.Dy, oDz = p.Dz;
         p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
         // a stale re-execution starts on the plane itself: its old point has no side
-        p.s_old = stale ? 0 : sgn_i(off);
+        const int side = stale ? 0 : sgn_i(off);
         // every operation first moves the photon onto the plane
         // (PhotonObject.py:149/198; Elements.py:167 for the detector)
         if (type == RTMC_TYPE_DUMP && stale) {
@@ -540,7 +666,6 @@ __device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<
             real t = -off * M<real>::rcp(dn);
             p.Lx += t * p.Dx; p.Ly += t * p.Dy; p.Lz += t * p.Dz;
         }
-        bool rotate = true;
         if (type == RTMC_TYPE_DUMP) {  // Elements.py:152-169
             p.status = RTMC_ST_DUMPED;
             bool counted = true;
@@ -549,66 +674,67 @@ __device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<
                 counted = g.u32(0) < sc.eqeT[(size_t)(info - 1) * sc.lay.n_wid + p.wid];
             }
             tally.dump(el_idx, p.wid, p.wid0, counted);
-            rotate = false;
-        } else {
-            bool reflect = true;
-            if (type == RTMC_TYPE_INTERFACE) {  // Elements.py:41-73
-                const int m1 = info & 0xFF, m2 = (info >> 8) & 0xFF;
-                const int other = (m.name_id == lds.mats[m1].name_id) ? m2 : m1;  // by name, Elements.py:45-48
-                const DevMat<real> &mo = lds.mats[other];
-                const real n1 = m.n, n2 = mo.n;
-                const real r = n1 * M<real>::rcp(n2);
-                const real c = M<real>::abs(dn);  // cos(theta_i) for unit D, as Elements.py:87 takes it
-                // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
-                const real cn = c * M<real>::rcp(dnorm);
-                const bool tir = (n1 > n2) & (cn * cn < real(1) - (n2 * n2) * M<real>::rcp(n1 * n1));
-                // the operation owns one draw event whether or not it needs variates
-                if (tir) g.skip(); else g.event();
-                if (!tir) {
-                    // Elements.py:84-109 Reflectance, with cos/sin taken algebraically
-                    real st2 = r * r * (real(1) - c * c);
-                    real ct = M<real>::sqrt(real(1) - st2);
-                    real a1 = n1 * c, a2 = n2 * ct, b1 = n2 * c, b2 = n1 * ct;
-                    real rs = (a1 - a2) * M<real>::rcp(a1 + a2);
-                    real rp = (b1 - b2) * M<real>::rcp(b1 + b2);
-                    real R_perp = rs * rs, R_par = rp * rp;
-                    normalize3(p.Ex, p.Ey, p.Ez);
-                    real kx = sgn * (p.Dy * nz - p.Dz * ny), ky = sgn * (p.Dz * nx - p.Dx * nz),
-                         kz = sgn * (p.Dx * ny - p.Dy * nx);
-                    real k2 = kx * kx + ky * ky + kz * kz;
-                    real R;
-                    if (k2 != real(0)) {
-                        real dp = (p.Ex * kx + p.Ey * ky + p.Ez * kz);
-                        real dp2 = dp * dp * M<real>::rcp(k2);
-                        R = (real(1) - dp2) * R_par + dp2 * R_perp;
-                    } else {
-                        real q = (n1 - n2) * M<real>::rcp(n1 + n2);
-                        R = q * q;
-                    }
-                    if (g.uniform(0) > R) {  // Elements.py:57-66 crossing
-                        reflect = false;
-                        // PhotonObject.py:199 Snell
-                        real cc = -dn;
-                        real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
-                        p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
-                        p.mat = other;
-                        p.reflected = false;
-                        if (mo.flags & 1)
-                            p.dist = free_path(lds.abs[mo.abs_slot * sc.lay.n_wid + p.wid], g.expo(1), sc.src.inv_scale);
-                        else
-                            p.dist = real(0);
-                    }
+            p.was_el = true;
+            p.iter++;
+            return STEP_ENDED;
+        }
+        bool reflect = true;
+        if (type == RTMC_TYPE_INTERFACE) {  // Elements.py:41-73
+            const int m1 = info & 0xFF, m2 = (info >> 8) & 0xFF;
+            const int other = (m.name_id == lds.mats[m1].name_id) ? m2 : m1;  // by name, Elements.py:45-48
+            const DevMat<real> &mo = lds.mats[other];
+            const real n1 = m.n, n2 = mo.n;
+            const real r = n1 * M<real>::rcp(n2);
+            const real c = M<real>::abs(dn);  // cos(theta_i) for unit D, as Elements.py:87 takes it
+            // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
+            const real cn = c * M<real>::rcp(dnorm);
+            const bool tir = (n1 > n2) & (cn * cn < real(1) - (n2 * n2) * M<real>::rcp(n1 * n1));
+            // the operation owns one draw event whether or not it needs variates
+            if (tir) g.skip(); else g.event();
+            if (!tir) {
+                // Elements.py:84-109 Reflectance, with cos/sin taken algebraically
+                real st2 = r * r * (real(1) - c * c);
+                real ct = M<real>::sqrt(real(1) - st2);
+                real a1 = n1 * c, a2 = n2 * ct, b1 = n2 * c, b2 = n1 * ct;
+                real rs = (a1 - a2) * M<real>::rcp(a1 + a2);
+                real rp = (b1 - b2) * M<real>::rcp(b1 + b2);
+                real R_perp = rs * rs, R_par = rp * rp;
+                normalize3(p.Ex, p.Ey, p.Ez);
+                real kx = sgn * (p.Dy * nz - p.Dz * ny), ky = sgn * (p.Dz * nx - p.Dx * nz),
+                     kz = sgn * (p.Dx * ny - p.Dy * nx);
+                real k2 = kx * kx + ky * ky + kz * kz;
+                real R;
+                if (k2 != real(0)) {
+                    real dp = (p.Ex * kx + p.Ey * ky + p.Ez * kz);
+                    real dp2 = dp * dp * M<real>::rcp(k2);
+                    R = (real(1) - dp2) * R_par + dp2 * R_perp;
+                } else {
+                    real q = (n1 - n2) * M<real>::rcp(n1 + n2);
+                    R = q * q;
                 }
-                if (reflect) p.reflected = true;
+                if (g.uniform(0) > R) {  // Elements.py:57-66 crossing
+                    reflect = false;
+                    // PhotonObject.py:199 Snell
+                    real cc = -dn;
+                    real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
+                    p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
+                    p.mat = other;
+                    p.reflected = false;
+                    if (mo.flags & 1)
+                        p.dist = free_path(lds.abs[mo.abs_slot * sc.lay.n_wid + p.wid], g.expo(1), sc.src.inv_scale);
+                    else
+                        p.dist = real(0);
+                }
             }
-            if (reflect) {  // PhotonObject.py:150 (line-based: the negative of the mirror direction)
-                real c2 = real(2) * dn;
-                p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
-                tally.bounce(el_idx);
-            }
+            if (reflect) p.reflected = true;
+        }
+        if (reflect) {  // PhotonObject.py:150 (line-based: the negative of the mirror direction)
+            real c2 = real(2) * dn;
+            p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
+            tally.bounce(el_idx);
         }
         // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old)
-        if (rotate) {
+        {
             real cx = p.Dy * oDz - p.Dz * oDy, cy = p.Dz * oDx - p.Dx * oDz, cz = p.Dx * oDy - p.Dy * oDx;
             real c2n = cx * cx + cy * cy + cz * cz;
             if (c2n != real(0)) {
@@ -628,20 +754,29 @@ __device__ __forceinline__ bool photon_step(const DevScene<real> &sc, const Lds<
             }
         }
         p.was_el = true;  // PhotonObject.py:143
+        set_admissibility(p, type, side, nx * p.Dx + ny * p.Dy + nz * p.Dz);
     }
 
     // ---- RayTrace.py:193-195 ------------------------------------------------
-    bool stop = (p.status == RTMC_ST_INTERNAL_CONVERTED) | (p.status == RTMC_ST_DUMPED) |
-                (p.iter >= sc.max_iter - 1);
+    const bool stop = p.iter >= sc.max_iter - 1;
     p.iter++;
-    return !stop;
+    return stop ? STEP_ENDED : STEP_CONTINUE;
+}
+
+// Loop control for an iteration that ended in an absorption, once the pathway
+// is known (RayTrace.py:193-195).
+template <typename real>
+__device__ __forceinline__ StepResult finish_absorbed_iteration(const DevScene<real> &sc, Photon<real> &p)
+{
+    const bool stop = (p.status == RTMC_ST_INTERNAL_CONVERTED) | (p.iter >= sc.max_iter - 1);
+    p.iter++;
+    return stop ? STEP_ENDED : STEP_CONTINUE;
 }
 
 // book-keeping when a photon has ended, RayTrace.py:197-199
 template <typename real, typename Tally>
 __device__ __forceinline__ void count_fate(const Photon<real> &p, Tally &tally)
 {
-    tally.scalar(ACC_PHOTONS);
     tally.scalar(ACC_STEPS, (unsigned long long)p.iter);
     if (p.absorbed_once) tally.scalar(ACC_ABS_ONCE);
     int which = p.status == RTMC_ST_INTERNAL_CONVERTED ? ACC_IC
