@@ -214,12 +214,11 @@ step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int 
         p.hitd = M<real>::inf();
         p.wid = b.wid[k]; p.wid0 = b.wid0[k];
         p.mat = b.material[k]; p.status = b.status[k]; p.last_el = b.last_element[k];
-        p.was_el = b.was_element[k] != 0; p.reflected = b.reflected[k] != 0;
+        p.flags = (b.was_element[k] != 0 ? F_WAS_EL : 0u) | (b.reflected[k] != 0 ? F_REFLECTED : 0u);
         p.iter = b.iterations[k];
-        p.absorbed_once = false;
         p.best_t = real(0);
         set_admissibility_forward(p);
-        if (p.was_el && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
+        if ((p.flags & F_WAS_EL) && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
             const DevElem<real> &le = lds.elems[p.last_el];
             double s = (double)le.nx * b.old_point[0][k] + (double)le.ny * b.old_point[1][k] +
                        (double)le.nz * b.old_point[2][k] - (double)le.d0;
@@ -251,7 +250,7 @@ step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int 
     b.old_point[0][k] = p.oldx; b.old_point[1][k] = p.oldy; b.old_point[2][k] = p.oldz;
     b.dist_left[k] = p.dist; b.hit_distance[k] = p.hitd;
     b.wid[k] = p.wid; b.wid0[k] = p.wid0; b.material[k] = p.mat; b.status[k] = p.status;
-    b.last_element[k] = p.last_el; b.was_element[k] = p.was_el; b.reflected[k] = p.reflected;
+    b.last_element[k] = p.last_el; b.was_element[k] = (p.flags & F_WAS_EL) != 0u; b.reflected[k] = (p.flags & F_REFLECTED) != 0u;
     b.iterations[k] = p.iter; b.tape_pos[k] = (int32_t)g.pos;
 }
 
@@ -352,6 +351,7 @@ template <typename real>
 struct DeviceImage {
     std::vector<DevElem<real>> elems;
     std::vector<HitRec<real>> hits;
+    int n_group[4];
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
     DevSource<real> src;
@@ -405,6 +405,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     for (int i = 0; i < n_el; i++) {
         const rtmc_element &e = d->elements[i];
         DevElem<real> &o = img.elems[i];
+        memset(&o, 0, sizeof o);
         auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
         o.nx = (real)e.normal[0]; o.ny = (real)e.normal[1]; o.nz = (real)e.normal[2];
         o.d0 = (real)dot(e.normal, e.support);
@@ -418,30 +419,46 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         if (e.type == RTMC_TYPE_INTERFACE) o.info = e.material1 | (e.material2 << 8);
         if (e.type == RTMC_TYPE_DUMP) o.info = e.eqe_table + 1;
     }
-    // axis-aligned rectangles get the short hit test
-    img.hits.resize(n_el);
+    // interface records carry what the operation needs to know about both media
     for (int i = 0; i < n_el; i++) {
         const rtmc_element &e = d->elements[i];
-        HitRec<real> &h = img.hits[i];
-        memset(&h, 0, sizeof h);
-        h.kind = 3;
-        auto axis_of = [](const double *v) {  // index of the only non-zero component if it is +-1
-            int k = -1;
-            for (int j = 0; j < 3; j++) {
-                if (v[j] == 0.0) continue;
-                if (k >= 0 || std::fabs(v[j]) != 1.0) return -1;
-                k = j;
+        if (e.type != RTMC_TYPE_INTERFACE) continue;
+        DevElem<real> &o = img.elems[i];
+        o.nid1 = d->materials[e.material1].name_id;
+        o.n1v = (real)d->materials[e.material1].n;
+        o.n2v = (real)d->materials[e.material2].n;
+        o.slots = (mat_abs_slot[e.material1] + 1) | ((mat_abs_slot[e.material2] + 1) << 16);
+    }
+    // nearest-hit table: axis-aligned rectangles grouped by axis, then the rest
+    auto axis_of = [](const double *v) {  // index of the only non-zero component if it is +-1
+        int k = -1;
+        for (int j = 0; j < 3; j++) {
+            if (v[j] == 0.0) continue;
+            if (k >= 0 || std::fabs(v[j]) != 1.0) return -1;
+            k = j;
+        }
+        return k;
+    };
+    img.hits.clear();
+    for (int group = 0; group < 4; group++) {
+        img.n_group[group] = 0;
+        for (int i = 0; i < n_el; i++) {
+            const rtmc_element &e = d->elements[i];
+            const int kn = axis_of(e.normal), k1 = axis_of(e.e1), k2 = axis_of(e.e2);
+            const bool aligned = kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2;
+            if ((aligned ? kn : 3) != group) continue;
+            HitRec<real> h;
+            memset(&h, 0, sizeof h);
+            h.index = i;
+            if (aligned) {
+                const int ai = (kn + 1) % 3, aj = (kn + 2) % 3;
+                h.p0 = (real)e.support[kn];
+                h.ci = (real)e.support[ai]; h.cj = (real)e.support[aj];
+                h.hi = (real)(k1 == ai ? e.half1 : e.half2);
+                h.hj = (real)(k1 == ai ? e.half2 : e.half1);
             }
-            return k;
-        };
-        const int kn = axis_of(e.normal), k1 = axis_of(e.e1), k2 = axis_of(e.e2);
-        if (kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2) {
-            const int ai = (kn + 1) % 3, aj = (kn + 2) % 3;
-            h.kind = kn;
-            h.p0 = (real)e.support[kn];
-            h.ci = (real)e.support[ai]; h.cj = (real)e.support[aj];
-            h.hi = (real)(k1 == ai ? e.half1 : e.half2);
-            h.hj = (real)(k1 == ai ? e.half2 : e.half1);
+            img.hits.push_back(h);
+            img.n_group[group]++;
         }
     }
     std::vector<DevMat<real>> mats(n_mat);
@@ -755,6 +772,7 @@ static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, cons
     DevScene<real> sc;
     sc.hits = (const HitRec<real> *)(sizeof(real) == 4 ? p.hits32 : p.hits64);
     sc.energy_fx = p.energy_fx;
+    for (int k = 0; k < 4; k++) sc.n_group[k] = img.n_group[k];
     sc.elems = (const DevElem<real> *)(sizeof(real) == 4 ? p.elems32 : p.elems64);
     sc.lds_image = (const uint32_t *)(sizeof(real) == 4 ? p.lds32 : p.lds64);
     sc.wl = p.wl;

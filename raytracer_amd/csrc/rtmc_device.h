@@ -31,26 +31,33 @@ namespace rtmc {
 // records shared between host (scene builder) and device
 // ---------------------------------------------------------------------------
 
-// One element as the optical operation sees it (and the general hit test).
+// One element as the optical operation sees it (first three 16-byte groups,
+// gathered per lane from LDS) and as the general hit test sees it.
 // plane: n.x = d0; in-plane coordinates t1 = a.x - c1, t2 = b.x - c2.
 template <typename real>
 struct DevElem {
     real nx, ny, nz, d0;
+    int32_t type;   // RTMC_TYPE_*
+    int32_t info;   // interface: material1 | material2 << 8; dump: eqe table + 1
+    int32_t nid1;   // interface: name id of material1 (Elements.py:45 compares names)
+    int32_t slots;  // interface: (absorption slot of material1 + 1) | (slot of material2 + 1) << 16
+    real n1v, n2v;  // interface: refractive indices of material1 / material2
+    real pad0, pad1;
     real ax, ay, az, c1;
     real bx, by, bz, c2;
-    real h1, h2;
-    int32_t type;  // RTMC_TYPE_*
-    int32_t info;  // interface: material1 | material2 << 8; dump: eqe table + 1
+    real h1, h2, pad2, pad3;
 };
 
-// The same element as the nearest-hit search sees it.  kind 0/1/2: the normal
-// is the x/y/z axis and the in-plane axes are the other two (i = kind+1,
-// j = kind+2 cyclically): plane coordinate p0, centre (ci, cj), half extents
-// (hi, hj).  kind 3: general orientation, use DevElem.
+// An element as the nearest-hit search sees it.  The table is grouped by the
+// orientation of the normal: first the rectangles normal to x, then y, then z
+// (in-plane axes i = k+1, j = k+2 cyclically: plane coordinate p0, centre
+// (ci, cj), half extents (hi, hj)), then those of general orientation (only
+// `index` is used, the test reads DevElem).  Inside a group the list order of
+// the scene is kept.
 template <typename real>
 struct HitRec {
     real p0, ci, cj, hi, hj;
-    int32_t kind;
+    int32_t index;  // position in the scene's element list
     int32_t pad[sizeof(real) == 4 ? 2 : 5];
 };
 
@@ -102,8 +109,9 @@ enum { ACC_STEPS = 0, ACC_ABS_ONCE, ACC_ABSORPTIONS, ACC_IC, ACC_DUMPED, ACC_CAP
 
 template <typename real>
 struct DevScene {
-    const HitRec<real> *hits;    // global, wave-uniform reads
+    const HitRec<real> *hits;    // global, wave-uniform reads; grouped x | y | z | general
     const DevElem<real> *elems;  // global copy for wave-uniform reads (general elements)
+    int32_t n_group[4];          // sizes of the four groups of `hits`
     const uint32_t *lds_image;   // elems | mats | abs | cdf, copied to LDS by every workgroup
     const double *wl;            // wavelength of each id
     const unsigned long long *energy_fx;  // fixed wavelength source: llrint(wl0 / wl[id] * 2^24) per id
@@ -243,8 +251,14 @@ struct Photon {
     int32_t last_el;  // RayTrace.FirstEl, -1 none
     int32_t status;
     int32_t iter;
-    bool adm_all, was_el, reflected, absorbed_once;
+    uint32_t flags;   // F_* bits
 };
+enum : uint32_t { F_ADM_ALL = 1u, F_WAS_EL = 2u, F_REFLECTED = 4u, F_ABS_ONCE = 8u };
+template <typename real>
+__device__ __forceinline__ void set_flag(Photon<real> &p, uint32_t bit, bool on)
+{
+    p.flags = on ? (p.flags | bit) : (p.flags & ~bit);
+}
 
 // Views into the LDS image.
 template <typename real>
@@ -296,8 +310,9 @@ __device__ __forceinline__ real free_path(const DevAbs<real> &a, real e, real in
 template <typename real>
 __device__ __forceinline__ void set_admissibility(Photon<real> &p, int type, int side, real nd)
 {
-    const bool want_same = type == RTMC_TYPE_MIRROR ? true : (type == RTMC_TYPE_INTERFACE ? p.reflected : false);
-    p.adm_all = (side == 0) & !want_same;
+    const bool want_same = type == RTMC_TYPE_MIRROR ? true
+                         : (type == RTMC_TYPE_INTERFACE ? (p.flags & F_REFLECTED) != 0u : false);
+    set_flag(p, F_ADM_ALL, (side == 0) & !want_same);
     p.adm_q = side == 0 ? real(0) : (want_same ? nd * real(side) : -nd * real(side));
 }
 
@@ -306,7 +321,7 @@ __device__ __forceinline__ void set_admissibility(Photon<real> &p, int type, int
 template <typename real>
 __device__ __forceinline__ void set_admissibility_forward(Photon<real> &p)
 {
-    p.adm_all = false;
+    p.flags &= ~F_ADM_ALL;
     p.adm_q = real(1);
 }
 
@@ -322,7 +337,7 @@ __device__ __forceinline__ void init_photon_common(const DevScene<real> &sc, Pho
     p.last_el = -1;
     p.status = RTMC_ST_START;
     p.iter = 0;
-    p.was_el = false; p.reflected = false; p.absorbed_once = false;
+    p.flags = 0u;
     set_admissibility_forward(p);
 }
 
@@ -502,6 +517,25 @@ __device__ __forceinline__ void renew_emit(const DevScene<real> &sc, const Lds<r
 }
 
 // ---------------------------------------------------------------------------
+// wave-uniform record loads
+// ---------------------------------------------------------------------------
+// The hit records never change while a kernel runs.  Reading them through the
+// constant address space tells the compiler so, and wave-uniform reads then go
+// through the scalar cache into SGPRs (s_load) even though the kernel also
+// issues atomics to global memory.
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T *ptr)
+{
+    static_assert(sizeof(T) % 4 == 0, "record size");
+    typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
+    const ConstWords w = (ConstWords)(uintptr_t)ptr;
+    union { T value; uint32_t words[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) u.words[i] = w[i];
+    return u.value;
+}
+
+// ---------------------------------------------------------------------------
 // nearest valid hit
 // ---------------------------------------------------------------------------
 // Geometries.py:32-52 Rectangle.FindIntersections for one element of general
@@ -531,6 +565,44 @@ __device__ __forceinline__ bool axis_hit(const HitRec<real> &r, real inv_dk, rea
     t = r.p0 * inv_dk + m_lk;
     real Bi = Li + t * Di, Bj = Lj + t * Dj;
     return (M<real>::abs(Bi - r.ci) <= r.hi) & (M<real>::abs(Bj - r.cj) <= r.hj);
+}
+
+// Running minimum of the nearest-hit search.
+template <typename real>
+struct Nearest {
+    real t;    // signed line parameter of the best candidate, +inf if none
+    int32_t e; // its element index, -1 if none
+};
+
+template <typename real>
+__device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real t, int index, real adm_q,
+                                         bool adm_all, int skip, real dnorm)
+{
+    bool ok = inside & ((t * adm_q > real(0)) | adm_all) & (index != skip) &
+              (M<real>::abs(t) < M<real>::abs(best.t));
+    if (M<real>::has_self_hit_eps) ok = ok & (M<real>::abs(t) * dnorm > M<real>::self_hit_eps);
+    best.t = ok ? t : best.t;
+    best.e = ok ? index : best.e;
+}
+
+// One group of axis-aligned rectangles.  The record of the next element is
+// requested before the current one is tested so that the scalar-cache latency
+// overlaps the arithmetic.
+template <typename real>
+__device__ __forceinline__ void scan_axis_group(const HitRec<real> *recs, int count, real inv_dk, real m_lk,
+                                                real Li, real Di, real Lj, real Dj, real adm_q, bool adm_all,
+                                                int skip, real dnorm, Nearest<real> &best)
+{
+    if (count <= 0) return;
+    HitRec<real> cur = load_uniform(recs);
+    for (int i = 0; i < count; i++) {
+        HitRec<real> nxt = cur;
+        if (i + 1 < count) nxt = load_uniform(recs + i + 1);
+        real t;
+        const bool inside = axis_hit(cur, inv_dk, m_lk, Li, Di, Lj, Dj, t);
+        consider(best, inside, t, cur.index, adm_q, adm_all, skip, dnorm);
+        cur = nxt;
+    }
 }
 
 // Tally sinks -----------------------------------------------------------------
@@ -583,25 +655,28 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
     const real inv_x = M<real>::rcp(p.Dx), inv_y = M<real>::rcp(p.Dy), inv_z = M<real>::rcp(p.Dz);
     const real m_x = -p.Lx * inv_x, m_y = -p.Ly * inv_y, m_z = -p.Lz * inv_z;
     const real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
-    const int skip = p.was_el ? p.last_el : -1;
-    real best_t = M<real>::inf();
-    int best_e = -1;
-    for (int e = 0; e < sc.n_el; e++) {
-        const HitRec<real> &r = sc.hits[e];  // wave-uniform address
-        real t;
-        bool ok;
-        switch (r.kind) {  // wave-uniform branch
-        case 0: ok = axis_hit(r, inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, t); break;
-        case 1: ok = axis_hit(r, inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, t); break;
-        case 2: ok = axis_hit(r, inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, t); break;
-        default: ok = rect_hit(sc.elems[e], p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t); break;
+    const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
+    const bool adm_all = (p.flags & F_ADM_ALL) != 0u;
+    Nearest<real> nearest;
+    nearest.t = M<real>::inf();
+    nearest.e = -1;
+    {
+        const HitRec<real> *recs = sc.hits;
+        scan_axis_group(recs, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm, nearest);
+        recs += sc.n_group[0];
+        scan_axis_group(recs, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm, nearest);
+        recs += sc.n_group[1];
+        scan_axis_group(recs, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm, nearest);
+        recs += sc.n_group[2];
+        for (int i = 0; i < sc.n_group[3]; i++) {
+            const int index = load_uniform(&recs[i].index);
+            real t;
+            const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
+            consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
         }
-        const bool adm = (t * p.adm_q > real(0)) | p.adm_all;
-        ok = ok & adm & (e != skip) & (M<real>::abs(t) < M<real>::abs(best_t));
-        if (M<real>::has_self_hit_eps) ok = ok & (M<real>::abs(t) * dnorm > M<real>::self_hit_eps);
-        best_t = ok ? t : best_t;
-        best_e = ok ? e : best_e;
     }
+    const real best_t = nearest.t;
+    const int best_e = nearest.e;
     const bool stale = best_e < 0;
     const int el_idx = stale ? p.last_el : best_e;
     p.hitd = stale ? M<real>::inf() : M<real>::abs(best_t) * dnorm;
@@ -621,8 +696,7 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
             p.dist -= p.hitd;
             p.status = RTMC_ST_START;
         } else {
-            p.absorbed_once = true;
-            p.was_el = false;
+            p.flags = (p.flags | F_ABS_ONCE) & ~F_WAS_EL;
             p.status = RTMC_ST_ABSORBED;
             p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
             // move the rest of the free path towards the candidate point; with
@@ -642,7 +716,7 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
         }
     } else {
         p.status = RTMC_ST_START;
-        p.was_el = true;
+        p.flags |= F_WAS_EL;
     }
 
     // ---- the element's ExecuteOperation -------------------------------------
@@ -674,16 +748,17 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
                 counted = g.u32(0) < sc.eqeT[(size_t)(info - 1) * sc.lay.n_wid + p.wid];
             }
             tally.dump(el_idx, p.wid, p.wid0, counted);
-            p.was_el = true;
+            p.flags |= F_WAS_EL;
             p.iter++;
             return STEP_ENDED;
         }
         bool reflect = true;
         if (type == RTMC_TYPE_INTERFACE) {  // Elements.py:41-73
-            const int m1 = info & 0xFF, m2 = (info >> 8) & 0xFF;
-            const int other = (m.name_id == lds.mats[m1].name_id) ? m2 : m1;  // by name, Elements.py:45-48
-            const DevMat<real> &mo = lds.mats[other];
-            const real n1 = m.n, n2 = mo.n;
+            // the medium on the far side, chosen by name (Elements.py:45-48)
+            const bool from1 = m.name_id == el.nid1;
+            const int other = from1 ? (info >> 8) & 0xFF : info & 0xFF;
+            const int other_slot = (from1 ? (el.slots >> 16) : (el.slots & 0xFFFF)) - 1;
+            const real n1 = m.n, n2 = from1 ? el.n2v : el.n1v;
             const real r = n1 * M<real>::rcp(n2);
             const real c = M<real>::abs(dn);  // cos(theta_i) for unit D, as Elements.py:87 takes it
             // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
@@ -719,14 +794,14 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
                     real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
                     p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
                     p.mat = other;
-                    p.reflected = false;
-                    if (mo.flags & 1)
-                        p.dist = free_path(lds.abs[mo.abs_slot * sc.lay.n_wid + p.wid], g.expo(1), sc.src.inv_scale);
+                    p.flags &= ~F_REFLECTED;
+                    if (other_slot >= 0)
+                        p.dist = free_path(lds.abs[other_slot * sc.lay.n_wid + p.wid], g.expo(1), sc.src.inv_scale);
                     else
                         p.dist = real(0);
                 }
             }
-            if (reflect) p.reflected = true;
+            if (reflect) p.flags |= F_REFLECTED;
         }
         if (reflect) {  // PhotonObject.py:150 (line-based: the negative of the mirror direction)
             real c2 = real(2) * dn;
@@ -753,7 +828,7 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
                 }
             }
         }
-        p.was_el = true;  // PhotonObject.py:143
+        p.flags |= F_WAS_EL;  // PhotonObject.py:143
         set_admissibility(p, type, side, nx * p.Dx + ny * p.Dy + nz * p.Dz);
     }
 
@@ -778,7 +853,7 @@ template <typename real, typename Tally>
 __device__ __forceinline__ void count_fate(const Photon<real> &p, Tally &tally)
 {
     tally.scalar(ACC_STEPS, (unsigned long long)p.iter);
-    if (p.absorbed_once) tally.scalar(ACC_ABS_ONCE);
+    if (p.flags & F_ABS_ONCE) tally.scalar(ACC_ABS_ONCE);
     int which = p.status == RTMC_ST_INTERNAL_CONVERTED ? ACC_IC
               : p.status == RTMC_ST_DUMPED ? ACC_DUMPED
               : p.status == RTMC_ST_LOST ? ACC_LOST : ACC_CAPPED;

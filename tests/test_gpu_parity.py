@@ -150,18 +150,39 @@ def _sigma(n, p):
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
 def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
-    """Same seed, same Philox stream, float64 on both sides: the integer
-    tallies agree except for photons that pass within rounding of an edge."""
+    """Same seed, same Philox stream, float64 on both sides: every integer
+    tally is identical except for the odd photon that passes within rounding
+    of an edge (device and host libm differ in the last bit)."""
     rt, s = scenes(name)
-    n = 20000
+    n = 200000
     gpu = s.run(n, seed=11, precision=_abi.F64)
     cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=11, threads=8)
-    for key in ("n_photons", "n_steps", "n_absorbed_once", "n_absorptions",
-                "n_internal_converted", "n_dumped", "n_capped", "n_lost"):
-        assert abs(int(gpu[key]) - int(cpu[key])) <= max(3, int(cpu[key]) // 2000), key
-    diff = np.abs(gpu["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()
-    assert diff <= 20, diff
     assert gpu["n_photons"] == n and gpu["n_lost"] == 0
+    moved = 0
+    for key in ("counter", "bounce", "spectral"):
+        moved += int(np.abs(gpu[key].astype(np.int64) - cpu[key].astype(np.int64)).sum())
+    for key in ("n_steps", "n_absorbed_once", "n_absorptions", "n_internal_converted", "n_dumped",
+                "n_capped", "n_stale_steps"):
+        moved += abs(int(gpu[key]) - int(cpu[key]))
+    assert moved <= 8, moved
+    # detector spectra: same photons in the same 1-nm bins
+    assert np.abs(gpu["spectrum"].astype(np.int64) - cpu["spectrum"].astype(np.int64)).sum() <= 8
+    assert np.abs(gpu["energy_fx"].astype(np.int64) - cpu["energy_fx"].astype(np.int64)).max() <= 8 << 24
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+def test_f32_follows_f64_photon_for_photon(scenes, name):
+    """float32 production kernels against the float64 instantiation on the
+    same 5e6 photons: a photon changes fate only when it passes within
+    float32 rounding of an edge or of the Fresnel threshold -- a few in 1e6."""
+    rt, s = scenes(name)
+    n = 5000000
+    a = s.run(n, seed=17, precision=_abi.F32)
+    b = s.run(n, seed=17, precision=_abi.F64)
+    moved = int(np.abs(a["counter"].astype(np.int64) - b["counter"].astype(np.int64)).sum())
+    moved += abs(int(a["n_internal_converted"]) - int(b["n_internal_converted"]))
+    assert moved <= n // 50000, moved
+    assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= n // 2000
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C1_open"])
