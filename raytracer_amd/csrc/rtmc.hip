@@ -31,7 +31,13 @@ constexpr int TRACE_BLOCK = 256;      // 4 waves per workgroup
 constexpr uint32_t WORK_CHUNK = 1024; // photon ids a wave takes from the global counter at a time
 
 template <typename real>
-__device__ __forceinline__ Lds<real> stage_lds(const DevScene<real> &sc, unsigned char *smem, int n_acc)
+__device__ __forceinline__ SceneArg<real> scene_ref(const DevScene<real> *ptr)
+{
+    return *(const DevScene<real> __attribute__((address_space(4))) *)(uintptr_t)ptr;
+}
+
+template <typename real>
+__device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char *smem, int n_acc)
 {
     const uint32_t words = sc.lay.acc / 4;
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem);
@@ -63,10 +69,11 @@ enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
 
 template <typename real>
 __global__ void __launch_bounds__(TRACE_BLOCK)
-trace_kernel(DevScene<real> sc, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
+trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
              unsigned long long *work)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    SceneArg<real> sc = scene_ref(scene);
     const int n_acc = ACC_SCALARS + 3 * sc.n_el + sc.n_el * (int)sc.lay.n_src_lds;
     Lds<real> lds = stage_lds(sc, smem, n_acc);
 
@@ -190,10 +197,11 @@ struct SoaDev {
 // rtmc_step_tape: one lane per photon, variates from the tape.
 template <typename real>
 __global__ void __launch_bounds__(TRACE_BLOCK)
-step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int launch,
+step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_steps, int launch,
                  const double *tape, const unsigned long long *tape_off, double *trace, int *overrun)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    SceneArg<real> sc = scene_ref(scene);
     Lds<real> lds = stage_lds(sc, smem, 0);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -256,9 +264,10 @@ step_tape_kernel(DevScene<real> sc, SoaDev b, uint32_t n, uint32_t n_steps, int 
 
 // rtmc_op_intersect: one lane per (ray, element)
 template <typename real>
-__global__ void intersect_kernel(DevScene<real> sc, uint32_t n, const double *loc, const double *dir,
+__global__ void intersect_kernel(const DevScene<real> *scene, uint32_t n, const double *loc, const double *dir,
                                  double *out)
 {
+    SceneArg<real> sc = scene_ref(scene);
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n * sc.n_el) return;
     const uint32_t k = (uint32_t)(idx / sc.n_el);
@@ -266,7 +275,7 @@ __global__ void intersect_kernel(DevScene<real> sc, uint32_t n, const double *lo
     real Lx = real(loc[3 * k]), Ly = real(loc[3 * k + 1]), Lz = real(loc[3 * k + 2]);
     real Dx = real(dir[3 * k]), Dy = real(dir[3 * k + 1]), Dz = real(dir[3 * k + 2]);
     real t;
-    bool ok = rect_hit(sc.elems[e], Lx, Ly, Lz, Dx, Dy, Dz, t);
+    bool ok = rect_hit(load_uniform(sc.elems + e), Lx, Ly, Lz, Dx, Dy, Dz, t);
     const double nan = __builtin_nan("");
     out[3 * idx] = ok ? (double)(Lx + t * Dx) : nan;
     out[3 * idx + 1] = ok ? (double)(Ly + t * Dy) : nan;
@@ -363,6 +372,7 @@ struct PerDevice {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     void *elems32 = nullptr, *elems64 = nullptr, *lds32 = nullptr, *lds64 = nullptr;
     void *hits32 = nullptr, *hits64 = nullptr;
+    void *scene32 = nullptr, *scene64 = nullptr;  // DevScene<float/double> in device memory
     unsigned long long *energy_fx = nullptr;
     double *wl = nullptr;
     uint32_t *eqeT = nullptr;
@@ -692,7 +702,7 @@ static void free_device(PerDevice &p)
 {
     if (!p.ready) return;
     void *bufs[] = {p.elems32, p.elems64, p.lds32, p.lds64, p.hits32, p.hits64, p.energy_fx,
-                    p.wl, p.eqeT, p.tallies, p.work};
+                    p.wl, p.eqeT, p.tallies, p.work, p.scene32, p.scene64};
     for (void *b : bufs) (void)hipFree(b);
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
@@ -719,6 +729,8 @@ RTMC_API int rtmc_scene_wavelengths(const rtmc_scene *s, int64_t *count, double 
     }
     return RTMC_OK;
 }
+
+static int upload_scene_structs(rtmc_scene *s, PerDevice &p);
 
 // upload the scene to `device` on first use; leaves that device current
 static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
@@ -762,7 +774,25 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
         HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace_kernel<double>, TRACE_BLOCK, s->img64.lay.total));
     }
+    {
+        int rc = upload_scene_structs(s, p);
+        if (rc) return rc;
+    }
     p.ready = true;
+    return RTMC_OK;
+}
+
+template <typename real>
+static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, const DeviceImage<real> &img);
+
+static int upload_scene_structs(rtmc_scene *s, PerDevice &p)
+{
+    DevScene<float> a = device_scene<float>(s, p, s->img32);
+    DevScene<double> b = device_scene<double>(s, p, s->img64);
+    HIP_TRY(hipMalloc(&p.scene32, sizeof a));
+    HIP_TRY(hipMalloc(&p.scene64, sizeof b));
+    HIP_TRY(hipMemcpy(p.scene32, &a, sizeof a, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p.scene64, &b, sizeof b, hipMemcpyHostToDevice));
     return RTMC_OK;
 }
 
@@ -820,10 +850,10 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
     if (f32)
         hipLaunchKernelGGL(trace_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           device_scene<float>(s, p, s->img32), tl, seed, first_photon, n_photons, p.work);
+                           (const DevScene<float> *)p.scene32, tl, seed, first_photon, n_photons, p.work);
     else
         hipLaunchKernelGGL(trace_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           device_scene<double>(s, p, s->img64), tl, seed, first_photon, n_photons, p.work);
+                           (const DevScene<double> *)p.scene64, tl, seed, first_photon, n_photons, p.work);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p.ev1, p.stream));
     std::vector<unsigned long long> host(p.tally_words);
@@ -951,11 +981,11 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
     const unsigned grid = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
     if (f32)
         hipLaunchKernelGGL(step_tape_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           device_scene<float>(s, p, s->img32), sd, n, n_steps, launch, (const double *)tbuf.ptr,
+                           (const DevScene<float> *)p.scene32, sd, n, n_steps, launch, (const double *)tbuf.ptr,
                            (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr);
     else
         hipLaunchKernelGGL(step_tape_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           device_scene<double>(s, p, s->img64), sd, n, n_steps, launch, (const double *)tbuf.ptr,
+                           (const DevScene<double> *)p.scene64, sd, n, n_steps, launch, (const double *)tbuf.ptr,
                            (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr);
     HIP_TRY(hipGetLastError());
     // results
@@ -997,10 +1027,10 @@ RTMC_API int rtmc_op_intersect(rtmc_scene *s, int device, int precision, uint32_
     HIP_TRY(hipMemcpyAsync(ddir.ptr, dir, 24 * (size_t)n, hipMemcpyHostToDevice, p.stream));
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == RTMC_F32)
-        hipLaunchKernelGGL(intersect_kernel<float>, dim3(grid), dim3(256), 0, p.stream, device_scene<float>(s, p, s->img32),
+        hipLaunchKernelGGL(intersect_kernel<float>, dim3(grid), dim3(256), 0, p.stream, (const DevScene<float> *)p.scene32,
                            n, (const double *)dl.ptr, (const double *)ddir.ptr, (double *)dout.ptr);
     else
-        hipLaunchKernelGGL(intersect_kernel<double>, dim3(grid), dim3(256), 0, p.stream, device_scene<double>(s, p, s->img64),
+        hipLaunchKernelGGL(intersect_kernel<double>, dim3(grid), dim3(256), 0, p.stream, (const DevScene<double> *)p.scene64,
                            n, (const double *)dl.ptr, (const double *)ddir.ptr, (double *)dout.ptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_points, dout.ptr, 24 * total, hipMemcpyDeviceToHost, p.stream));

@@ -129,6 +129,13 @@ struct DevTallies {
     unsigned long long *hist;       // n_el * n_wid
 };
 
+// The kernels receive the scene as a pointer to a device-resident DevScene and
+// read it through the constant address space: every field is then fetched
+// with a scalar load where it is used instead of being held in SGPRs for the
+// whole kernel (the struct is larger than the SGPR file can spare).
+template <typename real>
+using SceneArg = const DevScene<real> __attribute__((address_space(4))) &;
+
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
 // arithmetic helpers
@@ -173,10 +180,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        // one 32x32->64 multiply per lane pair of the round (v_mad_u64_u32)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
@@ -326,7 +334,7 @@ __device__ __forceinline__ void set_admissibility_forward(Photon<real> &p)
 }
 
 template <typename real>
-__device__ __forceinline__ void init_photon_common(const DevScene<real> &sc, Photon<real> &p)
+__device__ __forceinline__ void init_photon_common(SceneArg<real> sc, Photon<real> &p)
 {
     p.wid0 = p.wid;
     p.mat = sc.src.start_mat;
@@ -367,8 +375,8 @@ __device__ __forceinline__ void isotropic_direction(Photon<real> &p, Rng<real, T
     p.Dx = x; p.Dy = y; p.Dz = z;
 }
 
-template <typename real>
-__device__ __forceinline__ void apply_source_frame(const DevSource<real> &s, Photon<real> &p)
+template <typename real, typename Source>
+__device__ __forceinline__ void apply_source_frame(const Source &s, Photon<real> &p)
 {
     real x = p.Dx, y = p.Dy, z = M<real>::abs(p.Dz);  // PhotonObject.py:70-72
     p.Dx = x * s.frame[0] + y * s.frame[3] + z * s.frame[6];
@@ -379,10 +387,10 @@ __device__ __forceinline__ void apply_source_frame(const DevSource<real> &s, Pho
 
 // PhotonObject.py:49-97 ResetPhoton / GeneratePhoton
 template <typename real>
-__device__ __forceinline__ void launch_in_reference_order(const DevScene<real> &sc, const Lds<real> &lds,
+__device__ __forceinline__ void launch_in_reference_order(SceneArg<real> sc, const Lds<real> &lds,
                                                           Photon<real> &p, Rng<real, true> &g)
 {
-    const DevSource<real> &s = sc.src;
+    const auto &s = sc.src;
     p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
     if (s.dir_mode == 1) {
         isotropic_direction(p, g);
@@ -429,7 +437,7 @@ __device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE
 // point: donor/acceptor coin, pathway, re-emission, new free path -- with the
 // draws in the reference's order.
 template <typename real>
-__device__ __forceinline__ void emit_in_reference_order(const DevScene<real> &sc, const Lds<real> &lds,
+__device__ __forceinline__ void emit_in_reference_order(SceneArg<real> sc, const Lds<real> &lds,
                                                         Photon<real> &p, Rng<real, true> &g)
 {
     const DevMat<real> &m = lds.mats[p.mat];
@@ -489,10 +497,10 @@ __device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_
 // Launch (PhotonObject.py:49-97) with one event: words 0,1 direction (hemisphere
 // source only), 2 polarisation angle, 3 wavelength (spectrum source only).
 template <typename real>
-__device__ __forceinline__ void renew_launch(const DevScene<real> &sc, const Lds<real> &lds, Photon<real> &p,
+__device__ __forceinline__ void renew_launch(SceneArg<real> sc, const Lds<real> &lds, Photon<real> &p,
                                              Rng<real, false> &g)
 {
-    const DevSource<real> &s = sc.src;
+    const auto &s = sc.src;
     p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
     if (s.dir_mode == 1) {
         sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
@@ -508,7 +516,7 @@ __device__ __forceinline__ void renew_launch(const DevScene<real> &sc, const Lds
 // Re-emission (MonteCarloFRET.py:92-105,170-175 + PhotonObject.py:250/258)
 // with one event: words 0,1 direction, 2 polarisation angle, 3 free path.
 template <typename real>
-__device__ __forceinline__ void renew_emit(const DevScene<real> &sc, const Lds<real> &lds, const DevMat<real> &m,
+__device__ __forceinline__ void renew_emit(SceneArg<real> sc, const Lds<real> &lds, const DevMat<real> &m,
                                            Photon<real> &p, Rng<real, false> &g)
 {
     sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
@@ -644,7 +652,7 @@ enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 // (emit_in_reference_order / the renew block of the trace kernel) and then
 // calls finish_absorbed_iteration.
 template <typename real, bool TAPE, typename Tally>
-__device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, const Lds<real> &lds,
+__device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<real> &lds,
                                                   Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
 {
     // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
@@ -841,7 +849,7 @@ __device__ __forceinline__ StepResult photon_step(const DevScene<real> &sc, cons
 // Loop control for an iteration that ended in an absorption, once the pathway
 // is known (RayTrace.py:193-195).
 template <typename real>
-__device__ __forceinline__ StepResult finish_absorbed_iteration(const DevScene<real> &sc, Photon<real> &p)
+__device__ __forceinline__ StepResult finish_absorbed_iteration(SceneArg<real> sc, Photon<real> &p)
 {
     const bool stop = (p.status == RTMC_ST_INTERNAL_CONVERTED) | (p.iter >= sc.max_iter - 1);
     p.iter++;
