@@ -143,7 +143,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RTMC_LIBRARY") or LIB_PATH   # RTMC_LIBRARY: another build, for A/B runs
     if not os.path.isfile(p):
         raise RtmcError("HIP library %s is missing: build it with "
                         "`python -c 'import __graft_entry__ as g; g.build()'`" % p)

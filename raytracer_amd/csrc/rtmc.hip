@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -27,7 +28,10 @@ using namespace rtmc;
 // ---------------------------------------------------------------------------
 namespace {
 
-constexpr int TRACE_BLOCK = 256;      // 4 waves per workgroup
+#ifndef RTMC_TRACE_BLOCK
+#define RTMC_TRACE_BLOCK 256
+#endif
+constexpr int TRACE_BLOCK = RTMC_TRACE_BLOCK;  // threads per workgroup of the trace kernel
 constexpr uint32_t WORK_CHUNK = 1024; // photon ids a wave takes from the global counter at a time
 
 template <typename real>
@@ -37,20 +41,36 @@ __device__ __forceinline__ SceneArg<real> scene_ref(const DevScene<real> *ptr)
 }
 
 template <typename real>
-__device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char *smem, int n_acc)
+__device__ __forceinline__ HotScene<real> hot_scene(SceneArg<real> sc)
+{
+    HotScene<real> h;
+    h.hits = sc.hits; h.elems = sc.elems; h.eqeT = sc.eqeT;
+    for (int k = 0; k < 4; k++) h.n_group[k] = sc.n_group[k];
+    h.n_wid = (int32_t)sc.lay.n_wid; h.max_iter = sc.max_iter; h.inv_scale = sc.src.inv_scale;
+    return h;
+}
+
+template <typename real>
+__device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char *smem, bool with_accumulators)
 {
     const uint32_t words = sc.lay.acc / 4;
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem);
-    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = sc.lds_image[i];
-    unsigned long long *acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
-    for (int i = threadIdx.x; i < n_acc; i += blockDim.x) acc[i] = 0ull;
+    const uint32_t *src = sc.lds_image;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    if (with_accumulators) {  // acc and hist are adjacent
+        const uint32_t zero_words = (sc.lay.total - sc.lay.acc) / 4;
+        for (uint32_t i = threadIdx.x; i < zero_words; i += blockDim.x) dst[words + i] = 0u;
+    }
     __syncthreads();
     Lds<real> l;
     l.elems = reinterpret_cast<const DevElem<real> *>(smem + sc.lay.elems);
     l.mats = reinterpret_cast<const DevMat<real> *>(smem + sc.lay.mats);
     l.abs = reinterpret_cast<const DevAbs<real> *>(smem + sc.lay.abs);
     l.cdf = reinterpret_cast<const uint32_t *>(smem + sc.lay.cdf);
-    l.acc = acc;
+    l.fx = reinterpret_cast<const uint32_t *>(smem + sc.lay.fx);
+    l.bin = reinterpret_cast<const uint16_t *>(smem + sc.lay.bin);
+    l.acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
+    l.hist = reinterpret_cast<uint32_t *>(smem + sc.lay.hist);
     return l;
 }
 
@@ -67,21 +87,24 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // The grid is sized to the machine, not to n.
 enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
 
+#ifndef RTMC_TRACE_WAVES
+#define RTMC_TRACE_WAVES 1
+#endif
 template <typename real>
-__global__ void __launch_bounds__(TRACE_BLOCK)
+__global__ void __launch_bounds__(TRACE_BLOCK, RTMC_TRACE_WAVES)
 trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
              unsigned long long *work)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneArg<real> sc = scene_ref(scene);
-    const int n_acc = ACC_SCALARS + 3 * sc.n_el + sc.n_el * (int)sc.lay.n_src_lds;
-    Lds<real> lds = stage_lds(sc, smem, n_acc);
+    Lds<real> lds = stage_lds(sc, smem, true);
+    const HotScene<real> hot = hot_scene(sc);
 
     LdsTally<real> tally;
-    tally.acc = lds.acc; tally.hist = tl.hist; tally.wl = sc.wl; tally.energy_fx = sc.energy_fx;
-    tally.eqeT = sc.eqeT;
-    tally.n_el = sc.n_el; tally.n_wid = (int)sc.lay.n_wid; tally.n_src_lds = (int)sc.lay.n_src_lds;
+    tally.acc = lds.acc; tally.hist = lds.hist; tally.fx = lds.fx; tally.bin = lds.bin; tally.wl = sc.wl;
+    tally.n_el = sc.n_el; tally.n_bins = (int)sc.lay.n_bins;
     tally.fixed_source = sc.src.wl_mode == 0;
+    tally.lane_steps = 0ull; tally.lane_abs_once = 0u;
 
     Photon<real> p;
     Rng<real, false> g;
@@ -99,7 +122,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             bool emitting = false;
             if (need == NEED_EMIT) {
                 const DevMat<real> &m = lds.mats[p.mat];
-                const DevAbs<real> &a = lds.abs[m.abs_slot * sc.lay.n_wid + p.wid];
+                const DevAbs<real> &a = lds.abs[m.abs_slot * hot.n_wid + p.wid];
                 g.event();
                 const bool in_donor = g.u32(0) < a.coinT;
                 uint32_t v_lambda;
@@ -113,7 +136,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 } else {
                     p.status = RTMC_ST_INTERNAL_CONVERTED;
                 }
-                if (finish_absorbed_iteration(sc, p) == STEP_ENDED) {
+                if (finish_absorbed_iteration(hot, p) == STEP_ENDED) {
                     count_fate(p, tally);
                     need = NEED_LAUNCH;
                 } else {
@@ -150,7 +173,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             if (launching | emitting) {
                 g.event();
                 if (launching) renew_launch(sc, lds, p, g);
-                else renew_emit(sc, lds, lds.mats[p.mat], p, g);
+                else renew_emit(hot, lds, lds.mats[p.mat], p, g);
                 need = NEED_NONE;
             }
         }
@@ -159,7 +182,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             continue;
         }
         if (need == NEED_NONE) {
-            const StepResult r = photon_step(sc, lds, p, g, tally);
+            const StepResult r = photon_step(hot, lds, p, g, tally);
             if (r == STEP_ENDED) {
                 count_fate(p, tally);
                 need = NEED_LAUNCH;
@@ -169,20 +192,24 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
         }
     }
 
-    // flush the workgroup's accumulators
+    // flush: per-lane totals into LDS, then the workgroup's accumulators to HBM
+    if (tally.lane_steps) atomicAdd(&lds.acc[ACC_STEPS], tally.lane_steps);
+    if (tally.lane_abs_once) atomicAdd(&lds.acc[ACC_ABS_ONCE], (unsigned long long)tally.lane_abs_once);
     __syncthreads();
+    const int n_el = sc.n_el;
+    const int n_acc = ACC_SCALARS + 3 * n_el;
     for (int i = threadIdx.x; i < n_acc; i += blockDim.x) {
         unsigned long long v = lds.acc[i];
         if (v == 0ull) continue;
         if (i < ACC_SCALARS) atomicAdd(&tl.scalars[i], v);
-        else if (i < ACC_SCALARS + sc.n_el) atomicAdd(&tl.bounce[i - ACC_SCALARS], v);
-        else if (i < ACC_SCALARS + 2 * sc.n_el) atomicAdd(&tl.spectral[i - ACC_SCALARS - sc.n_el], v);
-        else if (i < ACC_SCALARS + 3 * sc.n_el) atomicAdd(&tl.energy_fx[i - ACC_SCALARS - 2 * sc.n_el], v);
-        else {
-            int j = i - ACC_SCALARS - 3 * sc.n_el;
-            int el = j / (int)sc.lay.n_src_lds, wid = j % (int)sc.lay.n_src_lds;
-            atomicAdd(&tl.hist[(size_t)el * sc.lay.n_wid + wid], v);
-        }
+        else if (i < ACC_SCALARS + n_el) atomicAdd(&tl.bounce[i - ACC_SCALARS], v);
+        else if (i < ACC_SCALARS + 2 * n_el) atomicAdd(&tl.spectral[i - ACC_SCALARS - n_el], v);
+        else atomicAdd(&tl.energy_fx[i - ACC_SCALARS - 2 * n_el], v);
+    }
+    const int n_hist = (int)(sc.lay.n_dump * sc.lay.n_bins);
+    for (int i = threadIdx.x; i < n_hist; i += blockDim.x) {
+        uint32_t v = lds.hist[i];
+        if (v) atomicAdd(&tl.hist[i], (unsigned long long)v);
     }
 }
 
@@ -202,7 +229,8 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
 {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneArg<real> sc = scene_ref(scene);
-    Lds<real> lds = stage_lds(sc, smem, 0);
+    Lds<real> lds = stage_lds(sc, smem, false);
+    const HotScene<real> hot = hot_scene(sc);
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     Rng<real, true> g;
@@ -237,10 +265,10 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
                    p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
     for (uint32_t it = 0; it < n_steps && alive; it++) {
-        StepResult r = photon_step(sc, lds, p, g, tally);
+        StepResult r = photon_step(hot, lds, p, g, tally);
         if (r == STEP_ABSORBED) {
-            emit_in_reference_order(sc, lds, p, g);
-            r = finish_absorbed_iteration(sc, p);
+            emit_in_reference_order(hot, lds, p, g);
+            r = finish_absorbed_iteration(hot, p);
         }
         alive = r == STEP_CONTINUE;
         if (trace) {
@@ -359,7 +387,7 @@ uint32_t threshold32(double q)
 template <typename real>
 struct DeviceImage {
     std::vector<DevElem<real>> elems;
-    std::vector<HitRec<real>> hits;
+    std::vector<HitChunk<real>> hits;
     int n_group[4];
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
@@ -373,7 +401,7 @@ struct PerDevice {
     void *elems32 = nullptr, *elems64 = nullptr, *lds32 = nullptr, *lds64 = nullptr;
     void *hits32 = nullptr, *hits64 = nullptr;
     void *scene32 = nullptr, *scene64 = nullptr;  // DevScene<float/double> in device memory
-    unsigned long long *energy_fx = nullptr;
+    void *ro_block = nullptr, *rw_block = nullptr; // the two allocations everything above lives in
     double *wl = nullptr;
     uint32_t *eqeT = nullptr;
     unsigned long long *tallies = nullptr;  // scalars | bounce | spectral | energy | hist
@@ -390,8 +418,11 @@ struct rtmc_scene {
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
-    std::vector<unsigned long long> energy_fx;  // fixed-wavelength source: energy increment per id
-    std::vector<int32_t> wid_bin;   // detector spectrum bin of each wavelength id
+    std::vector<uint32_t> energy_fx;   // single-line source: energy increment of each wavelength id
+    std::vector<uint16_t> wid_cbin;    // compact detector bin of each wavelength id
+    std::vector<int32_t> bins_used;    // compact bin -> 1-nm bin index (0 = 200 nm)
+    std::vector<int32_t> el_slot;      // detector slot of each element, -1 if not a detector
+    int n_dump = 0;
     std::vector<int32_t> el_eqe;    // per element: eqe table or -1
     DeviceImage<float> img32;
     DeviceImage<double> img64;
@@ -407,7 +438,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<int> &mat_cdfD, const std::vector<int> &mat_cdfA,
                  const std::vector<int> &cdf_wid_off, const std::vector<int> &mat_abs_slot,
                  const std::vector<HostTable> &absA, const std::vector<HostTable> &absD, int src_cdf,
-                 int n_src_lds, DeviceImage<real> &img)
+                 const std::vector<uint32_t> &energy_fx, const std::vector<uint16_t> &wid_cbin, int n_bins,
+                 const std::vector<int32_t> &el_slot, int n_dump, DeviceImage<real> &img)
 {
     const int n_el = d->n_elements, n_mat = d->n_materials;
     const int n_wid = (int)wl.size();
@@ -427,7 +459,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.type = e.type;
         o.info = 0;
         if (e.type == RTMC_TYPE_INTERFACE) o.info = e.material1 | (e.material2 << 8);
-        if (e.type == RTMC_TYPE_DUMP) o.info = e.eqe_table + 1;
+        if (e.type == RTMC_TYPE_DUMP) o.info = ((e.eqe_table + 1) & 0xFF) | (el_slot[i] << 8);
     }
     // interface records carry what the operation needs to know about both media
     for (int i = 0; i < n_el; i++) {
@@ -451,7 +483,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     };
     img.hits.clear();
     for (int group = 0; group < 4; group++) {
-        img.n_group[group] = 0;
+        std::vector<HitRec<real>> recs;
         for (int i = 0; i < n_el; i++) {
             const rtmc_element &e = d->elements[i];
             const int kn = axis_of(e.normal), k1 = axis_of(e.e1), k2 = axis_of(e.e2);
@@ -467,8 +499,20 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                 h.hi = (real)(k1 == ai ? e.half1 : e.half2);
                 h.hj = (real)(k1 == ai ? e.half2 : e.half1);
             }
-            img.hits.push_back(h);
-            img.n_group[group]++;
+            recs.push_back(h);
+        }
+        while (recs.size() % HIT_CHUNK) {  // padding that no ray can hit
+            HitRec<real> h;
+            memset(&h, 0, sizeof h);
+            h.hi = h.hj = (real)-1;
+            h.index = -1;
+            recs.push_back(h);
+        }
+        img.n_group[group] = (int)(recs.size() / HIT_CHUNK);
+        for (size_t c = 0; c < recs.size(); c += HIT_CHUNK) {
+            HitChunk<real> ch;
+            for (int k = 0; k < HIT_CHUNK; k++) ch.r[k] = recs[c + k];
+            img.hits.push_back(ch);
         }
     }
     std::vector<DevMat<real>> mats(n_mat);
@@ -521,7 +565,6 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
             DevAbs<real> &o = abs[(size_t)slot * n_wid + w];
             o.b_a = (real)b_a; o.b_d = (real)b_d;
             o.coinT = threshold32(b_d / (b_d + b_a));
-            o.pad = 0;
         }
     }
     std::vector<uint32_t> cdfT;
@@ -536,16 +579,22 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.mats = (uint32_t)off; off = align(off + sizeof(DevMat<real>) * std::max(1, n_mat));
     lay.abs = (uint32_t)off; off = align(off + sizeof(DevAbs<real>) * std::max<size_t>(1, abs.size()));
     lay.cdf = (uint32_t)off; off = align(off + 4 * cdfT.size());
+    lay.fx = (uint32_t)off; off = align(off + 4 * energy_fx.size());
+    lay.bin = (uint32_t)off; off = align(off + 2 * wid_cbin.size());
     lay.acc = (uint32_t)off;
     lay.n_wid = (uint32_t)n_wid;
-    lay.n_src_lds = (uint32_t)n_src_lds;
-    size_t n_acc = ACC_SCALARS + 3 * (size_t)n_el + (size_t)n_el * n_src_lds;
-    lay.total = (uint32_t)(off + 8 * n_acc);
+    lay.n_bins = (uint32_t)n_bins;
+    lay.n_dump = (uint32_t)n_dump;
+    const size_t n_acc = ACC_SCALARS + 3 * (size_t)n_el;
+    lay.hist = (uint32_t)(off + 8 * n_acc);
+    lay.total = (uint32_t)align(lay.hist + 4 * (size_t)std::max(1, n_dump * n_bins));
     img.lds.assign(off, 0);
     if (n_el) memcpy(img.lds.data() + lay.elems, img.elems.data(), sizeof(DevElem<real>) * n_el);
     if (n_mat) memcpy(img.lds.data() + lay.mats, mats.data(), sizeof(DevMat<real>) * n_mat);
     if (!abs.empty()) memcpy(img.lds.data() + lay.abs, abs.data(), sizeof(DevAbs<real>) * abs.size());
     memcpy(img.lds.data() + lay.cdf, cdfT.data(), 4 * cdfT.size());
+    memcpy(img.lds.data() + lay.fx, energy_fx.data(), 4 * energy_fx.size());
+    memcpy(img.lds.data() + lay.bin, wid_cbin.data(), 2 * wid_cbin.size());
 
     const rtmc_source &s = d->source;
     DevSource<real> &o = img.src;
@@ -588,6 +637,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     if (d->abi_version != RTMC_ABI_VERSION)
         return fail(RTMC_EINVAL, "description has ABI version %d, library %d", d->abi_version, RTMC_ABI_VERSION);
     if (d->n_elements < 1 || d->n_elements > 255) return fail(RTMC_ELIMIT, "1..255 elements supported, got %d", d->n_elements);
+    if (d->n_tables > 254) return fail(RTMC_ELIMIT, "at most 254 detection tables supported, got %d", d->n_tables);
     if (d->n_materials < 1 || d->n_materials > 255) return fail(RTMC_ELIMIT, "1..255 materials supported, got %d", d->n_materials);
     if (d->max_iterations < 1) return fail(RTMC_EINVAL, "max_iterations must be positive");
     if (!d->elements || !d->materials) return fail(RTMC_EINVAL, "null element or material array");
@@ -626,10 +676,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
         return (int)em.size() - 1;
     };
 
-    int n_src_lds = 0;
     if (src.wavelength_mode == 0) {
         wl.push_back(src.wavelength);  // id 0
-        n_src_lds = 1;
     } else if (src.wavelength_mode == 1) {
         HostTable t;
         int rc = get_table(d, src.spectrum, t, "source spectrum");
@@ -668,16 +716,30 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
     for (int i = 0; i < s->n_el; i++) s->el_eqe[i] = d->elements[i].type == RTMC_TYPE_DUMP ? d->elements[i].eqe_table : -1;
-    // detector bin of every wavelength: nearest of 200..3999 nm, Elements.py:159
+    // detector bin of every wavelength: nearest of 200..3999 nm, Elements.py:159;
+    // the device histogram only keeps the bins that can occur
     std::vector<double> bins(RTMC_SPECTRUM_BINS);
     for (int i = 0; i < RTMC_SPECTRUM_BINS; i++) bins[i] = RTMC_SPECTRUM_FIRST_NM + i;
-    s->wid_bin.resize(wl.size());
-    for (size_t w = 0; w < wl.size(); w++) s->wid_bin[w] = (int32_t)nearest_index(bins, wl[w]);
+    std::vector<int32_t> wid_bin(wl.size());
+    for (size_t w = 0; w < wl.size(); w++) wid_bin[w] = (int32_t)nearest_index(bins, wl[w]);
+    s->bins_used = wid_bin;
+    std::sort(s->bins_used.begin(), s->bins_used.end());
+    s->bins_used.erase(std::unique(s->bins_used.begin(), s->bins_used.end()), s->bins_used.end());
+    s->wid_cbin.resize(wl.size());
+    for (size_t w = 0; w < wl.size(); w++)
+        s->wid_cbin[w] = (uint16_t)(std::lower_bound(s->bins_used.begin(), s->bins_used.end(), wid_bin[w]) - s->bins_used.begin());
+    s->el_slot.assign(s->n_el, -1);
+    s->n_dump = 0;
+    for (int i = 0; i < s->n_el; i++)
+        if (d->elements[i].type == RTMC_TYPE_DUMP) s->el_slot[i] = s->n_dump++;
     // Elements.py:158 EnergyCounter += wl_start / wl, in units of 2^-24, for a single source line
-    s->energy_fx.assign(wl.size(), 0ull);
+    s->energy_fx.assign(wl.size(), 0u);
     if (src.wavelength_mode == 0)
-        for (size_t w = 0; w < wl.size(); w++)
-            s->energy_fx[w] = (unsigned long long)std::llrint(wl[0] / wl[w] * RTMC_ENERGY_FX_SCALE);
+        for (size_t w = 0; w < wl.size(); w++) {
+            double fx = std::llrint(wl[0] / wl[w] * RTMC_ENERGY_FX_SCALE);
+            if (fx > 4294967295.0) { delete s; return fail(RTMC_ELIMIT, "wavelength ratio %g too large", wl[0] / wl[w]); }
+            s->energy_fx[w] = (uint32_t)fx;
+        }
     // detection thresholds, Elements.py:164
     s->eqeT.assign(std::max<size_t>(1, (size_t)d->n_tables * wl.size()), 0xFFFFFFFFu);
     for (int t = 0; t < d->n_tables; t++) {
@@ -687,8 +749,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
         for (size_t w = 0; w < wl.size(); w++)
             s->eqeT[(size_t)t * wl.size() + w] = threshold32(q.y[nearest_index(q.x, wl[w])]);
     }
-    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, n_src_lds, s->img32);
-    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, n_src_lds, s->img64);
+    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img32);
+    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img64);
     if (s->img32.lay.total > 160 * 1024) {
         size_t need = s->img32.lay.total;
         delete s;
@@ -701,9 +763,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
 static void free_device(PerDevice &p)
 {
     if (!p.ready) return;
-    void *bufs[] = {p.elems32, p.elems64, p.lds32, p.lds64, p.hits32, p.hits64, p.energy_fx,
-                    p.wl, p.eqeT, p.tallies, p.work, p.scene32, p.scene64};
-    for (void *b : bufs) (void)hipFree(b);
+    (void)hipFree(p.ro_block);
+    (void)hipFree(p.rw_block);
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
     if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -746,23 +807,37 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
     HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p.ev0));
     HIP_TRY(hipEventCreate(&p.ev1));
-    auto upload = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, std::max<size_t>(bytes, 16));
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    // Two allocations per device: one for everything the kernels only read, one
+    // for what they update with atomics (tallies, work counter).  Sharing a
+    // cache line between the two makes every atomic evict read-only data that
+    // the scalar loads of all waves keep re-reading.
+    auto round_up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+    struct Piece { void **dst; const void *src; size_t bytes; };
+    const Piece pieces[] = {
+        {&p.elems32, s->img32.elems.data(), sizeof(DevElem<float>) * s->n_el},
+        {&p.elems64, s->img64.elems.data(), sizeof(DevElem<double>) * s->n_el},
+        {&p.hits32, s->img32.hits.data(), sizeof(HitChunk<float>) * s->img32.hits.size()},
+        {&p.hits64, s->img64.hits.data(), sizeof(HitChunk<double>) * s->img64.hits.size()},
+        {&p.lds32, s->img32.lds.data(), s->img32.lds.size()},
+        {&p.lds64, s->img64.lds.data(), s->img64.lds.size()},
+        {(void **)&p.wl, s->wl.data(), sizeof(double) * s->wl.size()},
+        {(void **)&p.eqeT, s->eqeT.data(), 4 * s->eqeT.size()},
+        {&p.scene32, nullptr, sizeof(DevScene<float>)},
+        {&p.scene64, nullptr, sizeof(DevScene<double>)},
     };
-    HIP_TRY(upload(&p.elems32, s->img32.elems.data(), sizeof(DevElem<float>) * s->n_el));
-    HIP_TRY(upload(&p.elems64, s->img64.elems.data(), sizeof(DevElem<double>) * s->n_el));
-    HIP_TRY(upload(&p.hits32, s->img32.hits.data(), sizeof(HitRec<float>) * s->n_el));
-    HIP_TRY(upload(&p.hits64, s->img64.hits.data(), sizeof(HitRec<double>) * s->n_el));
-    HIP_TRY(upload((void **)&p.energy_fx, s->energy_fx.data(), 8 * s->energy_fx.size()));
-    HIP_TRY(upload(&p.lds32, s->img32.lds.data(), s->img32.lds.size()));
-    HIP_TRY(upload(&p.lds64, s->img64.lds.data(), s->img64.lds.size()));
-    HIP_TRY(upload((void **)&p.wl, s->wl.data(), sizeof(double) * s->wl.size()));
-    HIP_TRY(upload((void **)&p.eqeT, s->eqeT.data(), 4 * s->eqeT.size()));
-    p.tally_words = ACC_SCALARS + 3 * (size_t)s->n_el + (size_t)s->n_el * s->wl.size();
-    HIP_TRY(hipMalloc((void **)&p.tallies, 8 * p.tally_words));
-    HIP_TRY(hipMalloc((void **)&p.work, 8));
+    size_t ro_bytes = 0;
+    for (const Piece &pc : pieces) ro_bytes += round_up(pc.bytes);
+    HIP_TRY(hipMalloc(&p.ro_block, ro_bytes));
+    size_t off = 0;
+    for (const Piece &pc : pieces) {
+        *pc.dst = (char *)p.ro_block + off;
+        if (pc.src && pc.bytes) HIP_TRY(hipMemcpy(*pc.dst, pc.src, pc.bytes, hipMemcpyHostToDevice));
+        off += round_up(pc.bytes);
+    }
+    p.tally_words = ACC_SCALARS + 3 * (size_t)s->n_el + (size_t)std::max(1, s->n_dump) * s->bins_used.size();
+    HIP_TRY(hipMalloc(&p.rw_block, round_up(8 * p.tally_words) + 4096));
+    p.tallies = (unsigned long long *)p.rw_block;
+    p.work = (unsigned long long *)((char *)p.rw_block + round_up(8 * p.tally_words));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     p.n_cu = prop.multiProcessorCount;
@@ -789,8 +864,6 @@ static int upload_scene_structs(rtmc_scene *s, PerDevice &p)
 {
     DevScene<float> a = device_scene<float>(s, p, s->img32);
     DevScene<double> b = device_scene<double>(s, p, s->img64);
-    HIP_TRY(hipMalloc(&p.scene32, sizeof a));
-    HIP_TRY(hipMalloc(&p.scene64, sizeof b));
     HIP_TRY(hipMemcpy(p.scene32, &a, sizeof a, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p.scene64, &b, sizeof b, hipMemcpyHostToDevice));
     return RTMC_OK;
@@ -800,8 +873,7 @@ template <typename real>
 static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, const DeviceImage<real> &img)
 {
     DevScene<real> sc;
-    sc.hits = (const HitRec<real> *)(sizeof(real) == 4 ? p.hits32 : p.hits64);
-    sc.energy_fx = p.energy_fx;
+    sc.hits = (const HitChunk<real> *)(sizeof(real) == 4 ? p.hits32 : p.hits64);
     for (int k = 0; k < 4; k++) sc.n_group[k] = img.n_group[k];
     sc.elems = (const DevElem<real> *)(sizeof(real) == 4 ? p.elems32 : p.elems64);
     sc.lds_image = (const uint32_t *)(sizeof(real) == 4 ? p.lds32 : p.lds64);
@@ -845,6 +917,9 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     uint64_t resident = (uint64_t)p.n_cu * (uint64_t)per_cu;
     unsigned grid = (unsigned)std::max<uint64_t>(1, std::min(wanted, resident));
 
+    if (getenv("RTMC_DEBUG"))
+        fprintf(stderr, "[rtmc] trace launch: %u workgroups of %d threads (%d per CU x %d CUs), %zu B LDS, %llu photons\n",
+                grid, TRACE_BLOCK, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
     HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
     HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
@@ -866,30 +941,33 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     const unsigned long long *sc = host.data();
     const unsigned long long *bounce = sc + ACC_SCALARS, *spectral = bounce + s->n_el,
                              *energy = spectral + s->n_el, *hist = energy + s->n_el;
-    out->n_photons += sc[ACC_IC] + sc[ACC_DUMPED] + sc[ACC_CAPPED] + sc[ACC_LOST];
+    const size_t n_bins = s->bins_used.size();
+    unsigned long long dumped = 0;
+    for (int e = 0; e < s->n_el; e++) {
+        out->bounce[e] += bounce[e];
+        out->energy_fx[e] += energy[e];
+        if (s->el_slot[e] < 0) continue;
+        unsigned long long total = 0;
+        for (size_t b = 0; b < n_bins; b++) {
+            unsigned long long c = hist[(size_t)s->el_slot[e] * n_bins + b];
+            if (!c) continue;
+            total += c;
+            out->spectrum[(size_t)e * RTMC_SPECTRUM_BINS + s->bins_used[b]] += c;
+        }
+        out->counter[e] += total;
+        dumped += total;
+        // Elements.py:161-165: without a detection table every photon counts
+        out->spectral[e] += s->el_eqe[e] >= 0 ? spectral[e] : total;
+    }
+    out->n_photons += sc[ACC_IC] + dumped + sc[ACC_CAPPED] + sc[ACC_LOST];
     out->n_steps += sc[ACC_STEPS];
     out->n_absorbed_once += sc[ACC_ABS_ONCE];
     out->n_absorptions += sc[ACC_ABSORPTIONS];
     out->n_internal_converted += sc[ACC_IC];
-    out->n_dumped += sc[ACC_DUMPED];
+    out->n_dumped += dumped;
     out->n_capped += sc[ACC_CAPPED];
     out->n_lost += sc[ACC_LOST];
     out->n_stale_steps += sc[ACC_STALE];
-    const size_t n_wid = s->wl.size();
-    for (int e = 0; e < s->n_el; e++) {
-        out->bounce[e] += bounce[e];
-        out->energy_fx[e] += energy[e];
-        unsigned long long total = 0;
-        for (size_t w = 0; w < n_wid; w++) {
-            unsigned long long c = hist[(size_t)e * n_wid + w];
-            if (!c) continue;
-            total += c;
-            out->spectrum[(size_t)e * RTMC_SPECTRUM_BINS + s->wid_bin[w]] += c;
-        }
-        out->counter[e] += total;
-        // Elements.py:161-165: without a detection table every photon counts
-        out->spectral[e] += s->el_eqe[e] >= 0 ? spectral[e] : total;
-    }
     return RTMC_OK;
 }
 

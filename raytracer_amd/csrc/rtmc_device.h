@@ -38,7 +38,7 @@ template <typename real>
 struct DevElem {
     real nx, ny, nz, d0;
     int32_t type;   // RTMC_TYPE_*
-    int32_t info;   // interface: material1 | material2 << 8; dump: eqe table + 1
+    int32_t info;   // interface: material1 | material2 << 8; dump: (eqe table + 1) | detector slot << 8
     int32_t nid1;   // interface: name id of material1 (Elements.py:45 compares names)
     int32_t slots;  // interface: (absorption slot of material1 + 1) | (slot of material2 + 1) << 16
     real n1v, n2v;  // interface: refractive indices of material1 / material2
@@ -59,6 +59,15 @@ struct HitRec {
     real p0, ci, cj, hi, hj;
     int32_t index;  // position in the scene's element list
     int32_t pad[sizeof(real) == 4 ? 2 : 5];
+};
+
+// The search reads the table four records at a time (one or two wide scalar
+// loads, one wait); every axis group is padded to a multiple of four with
+// records that can never be hit (negative half extents).
+constexpr int HIT_CHUNK = 4;
+template <typename real>
+struct alignas(64) HitChunk {
+    HitRec<real> r[HIT_CHUNK];
 };
 
 // One medium.
@@ -82,7 +91,6 @@ struct DevAbs {
     real b_a;        // acceptor attenuation coefficient [1/cm] (PhotonObject.py:288)
     real b_d;        // donor                                   (PhotonObject.py:289)
     uint32_t coinT;  // ceil(b_d / (b_d + b_a) * 2^32): "absorbed by the donor" threshold
-    uint32_t pad;
 };
 
 template <typename real>
@@ -97,24 +105,25 @@ struct DevSource {
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, abs, cdf, acc, total;
-    uint32_t n_wid;      // wavelength ids
-    uint32_t n_src_lds;  // wavelength ids whose detector histogram is kept in LDS
+    uint32_t elems, mats, abs, cdf, fx, bin, acc, hist, total;
+    uint32_t n_wid;   // wavelength ids
+    uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
+    uint32_t n_dump;  // detector elements
 };
 
-// Accumulators a workgroup keeps in LDS and flushes once (all uint64).
-// layout: scalars[ACC_SCALARS] bounce[n_el] spectral[n_el] energy[n_el] hist_src[n_el*n_src_lds]
-enum { ACC_STEPS = 0, ACC_ABS_ONCE, ACC_ABSORPTIONS, ACC_IC, ACC_DUMPED, ACC_CAPPED, ACC_LOST,
-       ACC_STALE, ACC_PHOTONS, ACC_SCALARS };
+// Accumulators a workgroup keeps in LDS and flushes once:
+//   uint64 acc[]: scalars[ACC_SCALARS] bounce[n_el] spectral[n_el] energy[n_el]
+//   uint32 hist[]: n_dump x n_bins detector histogram
+enum { ACC_STEPS = 0, ACC_ABS_ONCE, ACC_ABSORPTIONS, ACC_IC, ACC_CAPPED, ACC_LOST, ACC_STALE, ACC_SCALARS };
 
 template <typename real>
 struct DevScene {
-    const HitRec<real> *hits;    // global, wave-uniform reads; grouped x | y | z | general
+    const HitChunk<real> *hits;  // global, wave-uniform reads; grouped x | y | z | general
     const DevElem<real> *elems;  // global copy for wave-uniform reads (general elements)
-    int32_t n_group[4];          // sizes of the four groups of `hits`
+    int32_t n_group[4];          // chunks in each of the four groups of `hits`
     const uint32_t *lds_image;   // elems | mats | abs | cdf, copied to LDS by every workgroup
     const double *wl;            // wavelength of each id
-    const unsigned long long *energy_fx;  // fixed wavelength source: llrint(wl0 / wl[id] * 2^24) per id
+
     const uint32_t *eqeT;        // [n_eqe][n_wid] detection thresholds
     DevSource<real> src;
     LdsLayout lay;
@@ -126,7 +135,7 @@ struct DevTallies {
     unsigned long long *bounce;     // n_el
     unsigned long long *spectral;   // n_el
     unsigned long long *energy_fx;  // n_el
-    unsigned long long *hist;       // n_el * n_wid
+    unsigned long long *hist;       // n_dump * n_bins
 };
 
 // The kernels receive the scene as a pointer to a device-resident DevScene and
@@ -135,6 +144,18 @@ struct DevTallies {
 // whole kernel (the struct is larger than the SGPR file can spare).
 template <typename real>
 using SceneArg = const DevScene<real> __attribute__((address_space(4))) &;
+
+// The few scene values every loop iteration needs, copied out of the scene
+// once per kernel so that they stay in SGPRs.
+template <typename real>
+struct HotScene {
+    const HitChunk<real> *hits;
+    const DevElem<real> *elems;
+    const uint32_t *eqeT;
+    int32_t n_group[4];
+    int32_t n_wid, max_iter;
+    real inv_scale;
+};
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -148,6 +169,14 @@ template <> struct M<float> {
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float log(float x) { return ::logf(x); }
     static __device__ __forceinline__ void sincospi(float x, float *s, float *c) { ::sincospif(x, s, c); }
+    // sin/cos of 2 pi x for x in [0, 1): v_sin_f32 / v_cos_f32 take their argument in turns
+    static __device__ __forceinline__ void sincos_turns(float x, float *s, float *c)
+    {
+        *s = __builtin_amdgcn_sinf(x);
+        *c = __builtin_amdgcn_cosf(x);
+    }
+    // -log(1 - u) for the free path of a sampled photon: v_log_f32 (log2) scaled
+    static __device__ __forceinline__ float neg_log1m(float u) { return -0.6931471805599453f * __builtin_amdgcn_logf(1.0f - u); }
     static __device__ __forceinline__ float copysign(float m, float s) { return __builtin_copysignf(m, s); }
     static __device__ __forceinline__ float huge() { return 3.0e38f; }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
@@ -161,6 +190,8 @@ template <> struct M<double> {
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ void sincospi(double x, double *s, double *c) { ::sincospi(x, s, c); }
+    static __device__ __forceinline__ void sincos_turns(double x, double *s, double *c) { ::sincospi(2.0 * x, s, c); }
+    static __device__ __forceinline__ double neg_log1m(double u) { return -::log(1.0 - u); }
     static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
     static __device__ __forceinline__ double huge() { return 1.0e300; }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
@@ -203,12 +234,21 @@ struct Rng<real, false> {
     uint32_t k0, k1, id0, id1, ev;
     uint32_t w[4];
     __device__ __forceinline__ void skip() { ev++; }
+#ifdef RTMC_ABLATE_PHILOX
+    __device__ __forceinline__ void event()
+    {
+        uint32_t h = id0 * 0x9E3779B9u + ev * 0x85EBCA6Bu + k0;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+        w[0] = h; w[1] = h * 0x297A2D39u; w[2] = h ^ 0xA5A5A5A5u; w[3] = h * 0x9E3779B9u; ev++;
+    }
+#else
     __device__ __forceinline__ void event() { philox4x32_10(id0, id1, ev, 0u, k0, k1, w); ev++; }
+#endif
     // the uniform as an integer: floor(u * 2^32)
     __device__ __forceinline__ uint32_t u32(int slot) { return w[slot] & 0xFFFFFF00u; }
     __device__ __forceinline__ real uniform(int slot) { return real(w[slot] >> 8) * real(1.0 / 16777216.0); }
     // unit exponential, numpy legacy form -log(1 - U)
-    __device__ __forceinline__ real expo(int slot) { return -M<real>::log(real(1) - uniform(slot)); }
+    __device__ __forceinline__ real expo(int slot) { return M<real>::neg_log1m(uniform(slot)); }
     __device__ __forceinline__ void normal3(real &a, real &b, real &c) { a = b = c = real(0); }
     __device__ __forceinline__ bool consume_dead_draws() const { return false; }
 };
@@ -275,7 +315,10 @@ struct Lds {
     const DevMat<real> *mats;
     const DevAbs<real> *abs;
     const uint32_t *cdf;
+    const uint32_t *fx;    // per wavelength id: llrint(wl_source / wl * 2^24) for a single-line source
+    const uint16_t *bin;   // per wavelength id: compact detector bin
     unsigned long long *acc;
+    uint32_t *hist;
 };
 
 // number of thresholds <= v  ==  numpy.searchsorted(cdf, u, side='right')
@@ -437,11 +480,11 @@ __device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE
 // point: donor/acceptor coin, pathway, re-emission, new free path -- with the
 // draws in the reference's order.
 template <typename real>
-__device__ __forceinline__ void emit_in_reference_order(SceneArg<real> sc, const Lds<real> &lds,
+__device__ __forceinline__ void emit_in_reference_order(const HotScene<real> &sc, const Lds<real> &lds,
                                                         Photon<real> &p, Rng<real, true> &g)
 {
     const DevMat<real> &m = lds.mats[p.mat];
-    const DevAbs<real> &a = lds.abs[m.abs_slot * sc.lay.n_wid + p.wid];
+    const DevAbs<real> &a = lds.abs[m.abs_slot * sc.n_wid + p.wid];
     bool in_donor = g.u32(0) < a.coinT;  // PhotonObject.py:244
     uint32_t v_lambda;
     int outcome = fret_decide(m, g, in_donor, v_lambda);
@@ -459,7 +502,7 @@ __device__ __forceinline__ void emit_in_reference_order(SceneArg<real> sc, const
         p.status = RTMC_ST_INTERNAL_CONVERTED;
     }
     // PhotonObject.py:250/258: a free path is drawn whatever happened
-    p.dist = free_path(lds.abs[m.abs_slot * sc.lay.n_wid + p.wid], g.expo(0), sc.src.inv_scale);
+    p.dist = free_path(lds.abs[m.abs_slot * sc.n_wid + p.wid], g.expo(0), sc.inv_scale);
 }
 
 // ---------------------------------------------------------------------------
@@ -474,7 +517,7 @@ __device__ __forceinline__ void sphere_direction(real u_z, real u_phi, real &x, 
     real r2 = real(1) - z * z;
     real r = M<real>::sqrt(r2 > real(0) ? r2 : real(0));
     real s, c;
-    M<real>::sincospi(real(2) * u_phi, &s, &c);
+    M<real>::sincos_turns(u_phi, &s, &c);
     x = r * c; y = r * s;
 }
 
@@ -488,7 +531,7 @@ __device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_
     real a = real(-1) * M<real>::rcp(sg + Dz);
     real b = Dx * Dy * a;
     real s, c;
-    M<real>::sincospi(real(2) * u_psi, &s, &c);
+    M<real>::sincos_turns(u_psi, &s, &c);
     Ex = c * (real(1) + sg * Dx * Dx * a) + s * b;
     Ey = c * (sg * b) + s * (sg + Dy * Dy * a);
     Ez = c * (-sg * Dx) + s * (-Dy);
@@ -516,12 +559,12 @@ __device__ __forceinline__ void renew_launch(SceneArg<real> sc, const Lds<real> 
 // Re-emission (MonteCarloFRET.py:92-105,170-175 + PhotonObject.py:250/258)
 // with one event: words 0,1 direction, 2 polarisation angle, 3 free path.
 template <typename real>
-__device__ __forceinline__ void renew_emit(SceneArg<real> sc, const Lds<real> &lds, const DevMat<real> &m,
+__device__ __forceinline__ void renew_emit(const HotScene<real> &sc, const Lds<real> &lds, const DevMat<real> &m,
                                            Photon<real> &p, Rng<real, false> &g)
 {
     sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
     perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
-    p.dist = free_path(lds.abs[m.abs_slot * sc.lay.n_wid + p.wid], g.expo(3), sc.src.inv_scale);
+    p.dist = free_path(lds.abs[m.abs_slot * sc.n_wid + p.wid], g.expo(3), sc.inv_scale);
 }
 
 // ---------------------------------------------------------------------------
@@ -593,23 +636,20 @@ __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real 
     best.e = ok ? index : best.e;
 }
 
-// One group of axis-aligned rectangles.  The record of the next element is
-// requested before the current one is tested so that the scalar-cache latency
-// overlaps the arithmetic.
+// One group of axis-aligned rectangles, four records per scalar fetch.
 template <typename real>
-__device__ __forceinline__ void scan_axis_group(const HitRec<real> *recs, int count, real inv_dk, real m_lk,
+__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *chunks, int count, real inv_dk, real m_lk,
                                                 real Li, real Di, real Lj, real Dj, real adm_q, bool adm_all,
                                                 int skip, real dnorm, Nearest<real> &best)
 {
-    if (count <= 0) return;
-    HitRec<real> cur = load_uniform(recs);
-    for (int i = 0; i < count; i++) {
-        HitRec<real> nxt = cur;
-        if (i + 1 < count) nxt = load_uniform(recs + i + 1);
-        real t;
-        const bool inside = axis_hit(cur, inv_dk, m_lk, Li, Di, Lj, Dj, t);
-        consider(best, inside, t, cur.index, adm_q, adm_all, skip, dnorm);
-        cur = nxt;
+    for (int c = 0; c < count; c++) {
+        const HitChunk<real> ch = load_uniform(chunks + c);
+#pragma unroll
+        for (int k = 0; k < HIT_CHUNK; k++) {
+            real t;
+            const bool inside = axis_hit(ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, t);
+            consider(best, inside, t, ch.r[k].index, adm_q, adm_all, skip, dnorm);
+        }
     }
 }
 
@@ -619,30 +659,40 @@ __device__ __forceinline__ void scan_axis_group(const HitRec<real> *recs, int co
 template <typename real>
 struct LdsTally {
     unsigned long long *acc;
-    unsigned long long *hist;
+    uint32_t *hist;
+    const uint32_t *fx;
+    const uint16_t *bin;
     const double *wl;
-    const unsigned long long *energy_fx;
-    const uint32_t *eqeT;
-    int n_el, n_wid, n_src_lds;
+    int n_el, n_bins;
     bool fixed_source;
+    // per-lane totals, flushed once at the end of the kernel
+    unsigned long long lane_steps;
+    uint32_t lane_abs_once;
     __device__ __forceinline__ void scalar(int which, unsigned long long v = 1ull) { atomicAdd(&acc[which], v); }
     __device__ __forceinline__ void bounce(int el) { atomicAdd(&acc[ACC_SCALARS + el], 1ull); }
-    // Elements.py:152-165 Dump tallies (Counter and the 1-nm spectrum are derived on the host from `hist`)
-    __device__ __forceinline__ void dump(int el, int wid, int wid0, bool counted)
+    __device__ __forceinline__ void ended(int iter, bool absorbed_once)
     {
-        if (wid < n_src_lds) atomicAdd(&acc[ACC_SCALARS + 3 * n_el + el * n_src_lds + wid], 1ull);
-        else atomicAdd(&hist[(size_t)el * n_wid + wid], 1ull);
-        unsigned long long fx = fixed_source
-            ? energy_fx[wid]
+        lane_steps += (unsigned long long)iter;
+        lane_abs_once += absorbed_once ? 1u : 0u;
+    }
+    // Elements.py:152-165 Dump tallies.  Counter and the 1-nm spectrum come from
+    // the (detector, bin) histogram, which lives in LDS: detector hits are one
+    // per photon and scattered global atomics at that rate would bound the kernel.
+    __device__ __forceinline__ void dump(int el, int slot, int wid, int wid0, bool counted)
+    {
+        atomicAdd(&hist[slot * n_bins + bin[wid]], 1u);
+        unsigned long long e = fixed_source
+            ? (unsigned long long)fx[wid]
             : (unsigned long long)__double2ll_rn(wl[wid0] / wl[wid] * RTMC_ENERGY_FX_SCALE);
-        atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], fx);
+        atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], e);
         if (counted) atomicAdd(&acc[ACC_SCALARS + n_el + el], 1ull);
     }
 };
 struct NoTally {
     __device__ __forceinline__ void scalar(int, unsigned long long = 1ull) {}
     __device__ __forceinline__ void bounce(int) {}
-    __device__ __forceinline__ void dump(int, int, int, bool) {}
+    __device__ __forceinline__ void ended(int, bool) {}
+    __device__ __forceinline__ void dump(int, int, int, int, bool) {}
 };
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
@@ -652,7 +702,7 @@ enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 // (emit_in_reference_order / the renew block of the trace kernel) and then
 // calls finish_absorbed_iteration.
 template <typename real, bool TAPE, typename Tally>
-__device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<real> &lds,
+__device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, const Lds<real> &lds,
                                                   Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
 {
     // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
@@ -669,18 +719,23 @@ __device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<r
     nearest.t = M<real>::inf();
     nearest.e = -1;
     {
-        const HitRec<real> *recs = sc.hits;
-        scan_axis_group(recs, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm, nearest);
-        recs += sc.n_group[0];
-        scan_axis_group(recs, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm, nearest);
-        recs += sc.n_group[1];
-        scan_axis_group(recs, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm, nearest);
-        recs += sc.n_group[2];
-        for (int i = 0; i < sc.n_group[3]; i++) {
-            const int index = load_uniform(&recs[i].index);
-            real t;
-            const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
-            consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
+        const HitChunk<real> *chunks = sc.hits;
+        scan_axis_group(chunks, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm, nearest);
+        chunks += sc.n_group[0];
+        scan_axis_group(chunks, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm, nearest);
+        chunks += sc.n_group[1];
+        scan_axis_group(chunks, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm, nearest);
+        chunks += sc.n_group[2];
+        for (int c = 0; c < sc.n_group[3]; c++) {
+            const HitChunk<real> ch = load_uniform(chunks + c);
+#pragma unroll
+            for (int k = 0; k < HIT_CHUNK; k++) {
+                const int index = ch.r[k].index;
+                if (index < 0) continue;  // padding
+                real t;
+                const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
+                consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
+            }
         }
     }
     const real best_t = nearest.t;
@@ -751,11 +806,12 @@ __device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<r
         if (type == RTMC_TYPE_DUMP) {  // Elements.py:152-169
             p.status = RTMC_ST_DUMPED;
             bool counted = true;
-            if (info > 0) {
+            const int eqe = (info & 0xFF) - 1;
+            if (eqe >= 0) {
                 g.event();
-                counted = g.u32(0) < sc.eqeT[(size_t)(info - 1) * sc.lay.n_wid + p.wid];
+                counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
             }
-            tally.dump(el_idx, p.wid, p.wid0, counted);
+            tally.dump(el_idx, info >> 8, p.wid, p.wid0, counted);
             p.flags |= F_WAS_EL;
             p.iter++;
             return STEP_ENDED;
@@ -804,7 +860,7 @@ __device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<r
                     p.mat = other;
                     p.flags &= ~F_REFLECTED;
                     if (other_slot >= 0)
-                        p.dist = free_path(lds.abs[other_slot * sc.lay.n_wid + p.wid], g.expo(1), sc.src.inv_scale);
+                        p.dist = free_path(lds.abs[other_slot * sc.n_wid + p.wid], g.expo(1), sc.inv_scale);
                     else
                         p.dist = real(0);
                 }
@@ -817,6 +873,7 @@ __device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<r
             tally.bounce(el_idx);
         }
         // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old)
+#ifndef RTMC_ABLATE_ROTATE
         {
             real cx = p.Dy * oDz - p.Dz * oDy, cy = p.Dz * oDx - p.Dx * oDz, cz = p.Dx * oDy - p.Dy * oDx;
             real c2n = cx * cx + cy * cy + cz * cz;
@@ -836,6 +893,7 @@ __device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<r
                 }
             }
         }
+#endif
         p.flags |= F_WAS_EL;  // PhotonObject.py:143
         set_admissibility(p, type, side, nx * p.Dx + ny * p.Dy + nz * p.Dz);
     }
@@ -849,23 +907,22 @@ __device__ __forceinline__ StepResult photon_step(SceneArg<real> sc, const Lds<r
 // Loop control for an iteration that ended in an absorption, once the pathway
 // is known (RayTrace.py:193-195).
 template <typename real>
-__device__ __forceinline__ StepResult finish_absorbed_iteration(SceneArg<real> sc, Photon<real> &p)
+__device__ __forceinline__ StepResult finish_absorbed_iteration(const HotScene<real> &sc, Photon<real> &p)
 {
     const bool stop = (p.status == RTMC_ST_INTERNAL_CONVERTED) | (p.iter >= sc.max_iter - 1);
     p.iter++;
     return stop ? STEP_ENDED : STEP_CONTINUE;
 }
 
-// book-keeping when a photon has ended, RayTrace.py:197-199
+// book-keeping when a photon has ended, RayTrace.py:197-199 (detected photons
+// are counted through the detector histogram)
 template <typename real, typename Tally>
 __device__ __forceinline__ void count_fate(const Photon<real> &p, Tally &tally)
 {
-    tally.scalar(ACC_STEPS, (unsigned long long)p.iter);
-    if (p.flags & F_ABS_ONCE) tally.scalar(ACC_ABS_ONCE);
-    int which = p.status == RTMC_ST_INTERNAL_CONVERTED ? ACC_IC
-              : p.status == RTMC_ST_DUMPED ? ACC_DUMPED
-              : p.status == RTMC_ST_LOST ? ACC_LOST : ACC_CAPPED;
-    tally.scalar(which);
+    tally.ended(p.iter, (p.flags & F_ABS_ONCE) != 0u);
+    if (p.status != RTMC_ST_DUMPED)
+        tally.scalar(p.status == RTMC_ST_INTERNAL_CONVERTED ? ACC_IC
+                     : p.status == RTMC_ST_LOST ? ACC_LOST : ACC_CAPPED);
 }
 #endif  // __HIPCC__
 

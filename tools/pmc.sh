@@ -10,6 +10,7 @@ run() {
   name=$1; shift
   timeout -s KILL 180 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o $name -- python3 $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; exit 1; }
 }
+if [ -n "${4:-}" ]; then export RTMC_LIBRARY=$GRAFT_REPO_ROOT/$4; fi
 run a SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 run b SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_SCA
 run c FETCH_SIZE
