@@ -29,7 +29,7 @@ using namespace rtmc;
 namespace {
 
 #ifndef RTMC_TRACE_BLOCK
-#define RTMC_TRACE_BLOCK 256
+#define RTMC_TRACE_BLOCK 512
 #endif
 constexpr int TRACE_BLOCK = RTMC_TRACE_BLOCK;  // threads per workgroup of the trace kernel
 constexpr uint32_t WORK_CHUNK = 1024; // photon ids a wave takes from the global counter at a time
