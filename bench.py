@@ -39,6 +39,21 @@ def flops_per_iteration(n_elements):
     return 61 * n_elements + 250
 
 
+def measured_traffic(config, per_step):
+    """HBM bytes per launch from the committed counter passes (profiles/), if
+    they were taken on this workload and launch size; None otherwise."""
+    best = None
+    pdir = os.path.join(REPO, "profiles")
+    if os.path.isdir(pdir):
+        for name in sorted(os.listdir(pdir)):
+            if name.endswith("_traffic.json"):
+                with open(os.path.join(pdir, name)) as fh:
+                    t = json.load(fh)
+                if t.get("workload") == config and int(t.get("photons_per_launch", 0)) == per_step:
+                    best = float(t["hbm_bytes_per_launch"])
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,7 +148,8 @@ def main():
                        "internal_converted": tall["n_internal_converted"] / tall["n_photons"],
                        "capped": int(tall["n_capped"]), "lost": int(tall["n_lost"])},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "traffic": measured_traffic(args.config, per_step),
                          "kernel": "trace_kernel<float>", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "flop_per_iteration": flops_per_iteration(n_el),
                          "iterations_per_launch": iters_per_launch,
