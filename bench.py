@@ -63,7 +63,9 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=float, default=2.0e7)
+    ap.add_argument("--cpu-sample", type=float, default=1.5e8)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N ranks on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -72,10 +74,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = local_rank if args.device is None else args.device
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank
+        torch.cuda.set_device(device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(args.backend)
 
     from raytracer_amd import RayTrace, configs, _abi, distributed
     from raytracer_amd import scene as sc
@@ -110,7 +115,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tall = sc.tallies_to_dict(*block)
