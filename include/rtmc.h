@@ -112,6 +112,16 @@ typedef struct rtmc_material {
     double ol_DA, ol_AD; /* Foerster overlap sums (Materials.py:73-74)     */
     double P_ET_DA, P_ET_AD; /* transfer probabilities
                                 (MonteCarloFRET.py:195-237)                */
+    /* aligned acceptor dyes (is_aligned): the orientation integral of
+       PhotonObject.LambertBeerFullIntegral (PhotonObject.py:267-281) is
+       |psi_P (x^2 + y^2) + psi_Q z^2| for the unit field vector (x, y, z) in the
+       alignment frame; the host evaluates the two real constants from
+       align_S with the complex erf/erfi the reference uses (psi_P = 0,
+       psi_Q = 1 below the reference's 1e-10 threshold).  align_frame is
+       np.roll(MakeVectAxis(align_vect), 2, axis=1), row-major
+       (PhotonObject.py:295, RTUtils.py:51). */
+    double psi_P, psi_Q;
+    double align_frame[9];
     rtmc_table abs_A, abs_D, em_A, em_D;
 } rtmc_material;
 

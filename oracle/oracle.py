@@ -56,6 +56,9 @@ def lib():
         L.orc_check_sides.argtypes = [f64p, f64p, f64p, f64p]
         L.orc_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.orc_philox.restype = None
+        L.orc_set_aligned_special.argtypes = [C.c_void_p, C.c_int, f64p]
+        L.orc_orientation_integral.argtypes = [C.c_void_p, C.c_int, f64p]
+        L.orc_orientation_integral.restype = C.c_double
         _lib = L
     return _lib
 
@@ -77,6 +80,15 @@ class OracleScene:
         h = C.c_void_p()
         _check(lib().orc_scene_create(C.byref(self.packed.desc), C.byref(h)))
         self.handle = h
+        for i in range(self.packed.desc.n_materials):
+            m = self.packed.mat_array[i]
+            if m.is_absorber and m.is_aligned and m.align_S > 1e-10:
+                v = np.ascontiguousarray(aligned_special_values(m.align_S))
+                _check(lib().orc_set_aligned_special(h, i, _abi.f64_ptr(v)))
+
+    def orientation_integral(self, mat_index, n_E):
+        v = np.ascontiguousarray(n_E, dtype=np.float64)
+        return float(lib().orc_orientation_integral(self.handle, mat_index, _abi.f64_ptr(v)))
 
     @classmethod
     def from_raytrace(cls, rt):
@@ -146,6 +158,21 @@ class OracleScene:
         _check(lib().orc_material_info(self.handle, mat_index, _abi.f64_ptr(pet),
                                        _abi.f64_ptr(cdf_a), _abi.f64_ptr(cdf_d)))
         return pet, cdf_a, cdf_d
+
+
+def aligned_special_values(S):
+    """The scipy.special values the reference's LambertBeerFullIntegral
+    (PhotonObject.py:273) evaluates for order parameter S, flattened as
+    orc_set_aligned_special expects them."""
+    from scipy import special
+    a = 2.221441469079183 / S
+    b1, b2 = 0.7071067811865475 * S, 2.1213203435596424 * S
+    z = [special.erf(a - 1j * b1), special.erf(a + 1j * b1),
+         special.erf(a - 1j * b2), special.erf(a + 1j * b2)]
+    out = []
+    for c in z:
+        out += [c.real, c.imag]
+    return np.array(out + [float(special.erfi(b1)), float(special.erfi(b2))], dtype=np.float64)
 
 
 def op_interface(S, n, n1, n2, L, D, E):

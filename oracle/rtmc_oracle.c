@@ -25,6 +25,7 @@
  *
  * Reference file:line citations are given at each function.
  */
+#include <complex.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -69,6 +70,13 @@ typedef struct {
     double cdf_p[3], cdf_pA[3];
     int n_p;
     double P_ET_DA, P_ET_AD;
+    /* aligned acceptors: special-function values of LambertBeerFullIntegral
+       (supplied by the test harness from scipy, the library the reference calls)
+       and roll(MakeVectAxis(AlignVect), 2, axis=1) */
+    int have_special;
+    double complex erf_m1, erf_p1, erf_m2, erf_p2;
+    double erfi_1, erfi_2;
+    double frame[3][3];
 } omat_t;
 
 typedef struct orc_scene {
@@ -177,6 +185,28 @@ static void generate_molecules(omat_t *M)
     }
 }
 
+/* np.roll(RTU.MakeVectAxis(v), 2, axis=1) (RTUtils.py:25-42): columns n1, n2, v */
+static void z_axis_frame(const double *v, double tm[3][3])
+{
+    double nv[3] = {1, 0, 0};
+    if (v[0] == 1 && v[1] == 0 && v[2] == 0) { nv[0] = 0; nv[1] = 1; }
+    double n1[3], n2[3];
+    cross3(v, nv, n1);
+    double n = norm3(n1);
+    n1[0] /= n; n1[1] /= n; n1[2] /= n;
+    cross3(v, n1, n2);
+    n = norm3(n2);
+    n2[0] /= n; n2[1] /= n; n2[2] /= n;
+    for (int i = 0; i < 3; i++) { tm[i][0] = n1[i]; tm[i][1] = n2[i]; tm[i][2] = v[i]; }
+}
+/* np.dot(tm, v) */
+static void frame_apply(double tm[3][3], double *v)
+{
+    double o[3];
+    for (int i = 0; i < 3; i++) o[i] = dot3(tm[i], v);
+    v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+}
+
 static void cdf3(const double *p, int n, double *cdf)
 {
     double c = 0;
@@ -226,11 +256,7 @@ ORC_EXPORT int orc_scene_create(const rtmc_scene_desc *d, orc_scene **out)
         omat_t *M = &s->mat[i];
         M->m = d->materials[i];
         if (!M->m.is_absorber) continue;
-        if (M->m.is_aligned) {
-            snprintf(g_err, sizeof g_err, "material %d: aligned dyes not restated yet", i);
-            orc_scene_destroy(s);
-            return RTMC_EUNSUPPORTED;
-        }
+        if (M->m.is_aligned) z_axis_frame(M->m.align_vect, M->frame);
         if (tab_copy(&M->abs_A, d, M->m.abs_A) || tab_copy(&M->abs_D, d, M->m.abs_D) ||
             tab_copy(&M->em_A, d, M->m.em_A) || tab_copy(&M->em_D, d, M->m.em_D)) {
             snprintf(g_err, sizeof g_err, "material %d: table out of range", i);
@@ -264,6 +290,50 @@ ORC_EXPORT int orc_scene_create(const rtmc_scene_desc *d, orc_scene **out)
     }
     *out = s;
     return RTMC_OK;
+}
+
+/* erf(a - i b1), erf(a + i b1), erf(a - i b2), erf(a + i b2) as (re, im) pairs,
+ * then erfi(b1), erfi(b2): the six scipy.special values PhotonObject.py:273
+ * evaluates for this material's order parameter */
+ORC_EXPORT int orc_set_aligned_special(orc_scene *s, int mat, const double *v)
+{
+    if (!s || mat < 0 || mat >= s->n_mat) return RTMC_EINVAL;
+    omat_t *M = &s->mat[mat];
+    M->erf_m1 = v[0] + v[1] * I; M->erf_p1 = v[2] + v[3] * I;
+    M->erf_m2 = v[4] + v[5] * I; M->erf_p2 = v[6] + v[7] * I;
+    M->erfi_1 = v[8]; M->erfi_2 = v[9];
+    M->have_special = 1;
+    return RTMC_OK;
+}
+
+/* PhotonObject.py:267-281 LambertBeerFullIntegral */
+static double lambert_beer_full_integral(const omat_t *M, const double *nE)
+{
+    double x = nE[0], y = nE[1], z = nE[2];
+    double S = M->m.align_S, ol;
+    if (S > 1e-10) {
+        double x2 = x * x, y2 = y * y, z2 = z * z;
+        double complex t1 =
+            (-0.2349964007466563 * I) * (x2 + y2 + (2 / 3.0) * z2) * M->erf_m1 +
+            (0.2349964007466563 * I) * (x2 + y2 + (2 / 3.0) * z2) * M->erf_p1 +
+            (0.4699928014933126 * x2 + 0.4699928014933126 * y2 + 0.313328534328875 * z2) * M->erfi_1;
+        double complex t2 =
+            (0.07833213358221876 * I) * (x2 + y2 - 2 * z2) * M->erf_m2 -
+            (0.07833213358221876 * I) * (x2 + y2 - 2 * z2) * M->erf_p2 +
+            (-0.15666426716443752 * x2 - 0.15666426716443752 * y2 + 0.31332853432887503 * z2) * M->erfi_2;
+        ol = cabs(1 / S * (exp(-0.5 * S) * t1 + exp(-4.5 * (S * S)) * t2));
+    } else {
+        const double ez[3] = {0, 0, 1};
+        double d = dot3(nE, ez);
+        ol = d * d;
+    }
+    return ol < 1e-10 ? 0.0 : ol;
+}
+
+/* exported for tests */
+ORC_EXPORT double orc_orientation_integral(const orc_scene *s, int mat, const double *nE)
+{
+    return lambert_beer_full_integral(&s->mat[mat], nE);
 }
 
 /* exported for tests: transfer probabilities and emission CDFs as restated */
@@ -343,6 +413,7 @@ typedef struct {
     double L[3], D[3], E[3];
     double wl, wl0, dist_left;
     int mat, status, was_element, reflected;
+    double psi;                    /* Photon.Psi, set whenever a free path is drawn in an aligned medium */
     double sgn;
     double op_S[3], op_n[3];       /* Photon.OperationPlane              */
     double old_point[3];           /* Photon.OldPoint                    */
@@ -401,15 +472,24 @@ static void perpendicular(const double *D, double u_psi, double *E)
     E[2] = c * (-sg * D[0]) + s * (-D[1]);
 }
 
-/* PhotonObject.py:283-305 LamBeerDistance (non-aligned) */
+/* PhotonObject.py:283-305 LamBeerDistance */
 static void lambeer_distance(const orc_scene *s, ph_t *p, rng_t *g, int slot)
 {
-    const omat_t *M = &s->mat[p->mat];
+    omat_t *M = &s->mat[p->mat];
     if (M->m.is_absorber) {
         double ea = M->abs_A.y[find_closest(M->abs_A.x, M->abs_A.len, p->wl)];
         double ed = M->abs_D.y[find_closest(M->abs_D.x, M->abs_D.len, p->wl)];
         double b_a = M->m.conc_a * 1e-3 * M->m.emax_A * log(10.0) * fmax(1e-99, ea);
         double b_d = M->m.conc_b * 1e-3 * M->m.emax_D * log(10.0) * fmax(1e-99, ed);
+        if (M->m.is_aligned) { /* :291-302 */
+            double nE[3];
+            for (int j = 0; j < 3; j++) /* np.dot(E, tm): row vector times matrix */
+                nE[j] = fma(p->E[2], M->frame[2][j], fma(p->E[1], M->frame[1][j], p->E[0] * M->frame[0][j]));
+            double n = norm3(nE);
+            nE[0] /= n; nE[1] /= n; nE[2] /= n;
+            p->psi = lambert_beer_full_integral(M, nE);
+            b_a *= p->psi * 3.0;
+        }
         double scale = 1.0 / (b_a + b_d);
         p->dist_left = (1 / s->src.scale_factor) * (scale * rng_exponential(g, slot));
     } else
@@ -542,12 +622,80 @@ static void emit_philox(ph_t *p, rng_t *g)
     perpendicular(p->D, u24(g->w[2]), p->E);
 }
 
-/* MonteCarloFRET.py:63-193 RunSimulation (non-aligned acceptor).  `have_block`:
+/* MonteCarloFRET.py:124-162: fluorescence of an aligned acceptor.
+ * Tape mode draws in the reference's order (RTUtils.py:56-100 rejection
+ * sampling of sin^3, RTUtils.py:45-54 Gaussian tilt, optional azimuth of the
+ * emission dipole, optional random polarisation, wavelength).  Philox mode
+ * samples the same laws from two events:
+ *   event A: w0 polar angle by the closed-form inverse of the sin^3 CDF,
+ *            w1 its azimuth, (w2, w3) Box-Muller normal of the tilt;
+ *   event B: w0 tilt azimuth, w1 dipole azimuth, w2 polarisation angle,
+ *            w3 free path (drawn by the caller). */
+static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
+{
+    omat_t *M = &s->mat[p->mat];
+    const double pi = 3.141592653589793;
+    double sx, cx, psi_a, theta, phi, ph = 0, u_pol = 0, u_lambda = 0;
+    if (g->tape_mode) {
+        double ux = tape_next(g) * pi, uy = tape_next(g);
+        while (uy > pow(sin(ux), 3) && !g->overrun) { ux = tape_next(g) * pi; uy = tape_next(g); }
+        psi_a = tape_next(g) * 2 * pi;
+        sx = sin(ux); cx = cos(ux);
+        theta = M->m.align_S * tape_next(g);
+        phi = tape_next(g) * 2.0 * pi;
+    } else {
+        rng_event(g);
+        /* F(c) = (2 - 3c + c^3)/4 for c = cos(x); the root of c^3 - 3c + 2 - 4u in [-1, 1] */
+        cx = 2.0 * cos((acos(2.0 * u24(g->w[0]) - 1.0) + 4.0 * pi) / 3.0);
+        double s2 = 1.0 - cx * cx;
+        sx = sqrt(s2 > 0 ? s2 : 0.0);
+        psi_a = 2 * pi * u24(g->w[1]);
+        double r = sqrt(-2.0 * log(((double)(g->w[2] >> 8) + 1.0) * (1.0 / 16777216.0)));
+        theta = M->m.align_S * (r * cos(2 * pi * u24(g->w[3])));
+        rng_event(g);
+        phi = 2 * pi * u24(g->w[0]);
+        ph = 2 * pi * u24(g->w[1]);
+        u_pol = u24(g->w[2]);
+        u_lambda = 0; /* the acceptor wavelength comes from the absorption event, see fret_event */
+    }
+    double D[3] = {sx * cos(psi_a), sx * sin(psi_a), cx};
+    double vm[3] = {sin(theta) * cos(phi), sin(theta) * sin(phi), cos(theta)};
+    frame_apply(M->frame, vm);
+    double n = norm3(vm);
+    vm[0] /= n; vm[1] /= n; vm[2] /= n;
+    double tm[3][3];
+    z_axis_frame(vm, tm);
+    if (M->m.abs_em_angle > 0) { /* :139-149 */
+        double th = (M->m.abs_em_angle / 180.0) * pi;
+        if (g->tape_mode) ph = tape_next(g) * 2 * pi;
+        double v[3] = {sin(th) * cos(ph), sin(th) * sin(ph), cos(th)};
+        double etm[3][3];
+        z_axis_frame(v, etm);
+        frame_apply(etm, D);
+    }
+    frame_apply(tm, D);
+    n = norm3(D);
+    p->D[0] = D[0] / n; p->D[1] = D[1] / n; p->D[2] = D[2] / n;
+    if (s->src.respect_polarization) { /* PhotonObject.py:100-105 */
+        double v1[3], v2[3];
+        cross3(vm, p->D, v1);
+        cross3(p->D, v1, v2);
+        n = norm3(v2);
+        p->E[0] = v2[0] / n; p->E[1] = v2[1] / n; p->E[2] = v2[2] / n;
+    } else if (g->tape_mode)
+        polarization_random(p, g, p->D);
+    else
+        perpendicular(p->D, u_pol, p->E);
+    if (g->tape_mode) u_lambda = tape_next(g);
+    return u_lambda;
+}
+
+/* MonteCarloFRET.py:63-193 RunSimulation.  `have_block`:
  * the caller has already opened the draw event (its word 0 was the
  * donor/acceptor coin). */
 static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int have_block)
 {
-    const omat_t *M = &s->mat[p->mat];
+    omat_t *M = &s->mat[p->mat];
     for (;;) {
         double u_lambda = 0;
         if (!have_block) rng_event(g);
@@ -573,6 +721,13 @@ static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int 
         }
         /* :110-119 acceptor excited (directly or by transfer) */
         int pa = (int)cdf_pick(M->cdf_pA, 3, rng_uniform(g, 2));
+        if (pa == 0 && M->m.is_aligned) { /* :124-162 */
+            double ut = aligned_acceptor_emission(s, p, g);
+            if (g->tape_mode) u_lambda = ut;
+            p->wl = emit_wavelength(M, 0, u_lambda);
+            p->status = RTMC_ST_REEMITTED_ACCEPTOR;
+            return;
+        }
         if (pa == 0) {
             /* :170-175 direction, polarisation, wavelength */
             if (g->tape_mode) {
@@ -614,6 +769,7 @@ static void check_absorption(const orc_scene *s, ph_t *p, rng_t *g, const double
             double ea = M->abs_A.y[find_closest(M->abs_A.x, M->abs_A.len, p->wl)];
             double b_d = M->m.conc_b * 1e-3 * log(10.0) * M->m.emax_D * fmax(1e-99, ed);
             double b_a = M->m.conc_a * 1e-3 * log(10.0) * M->m.emax_A * fmax(1e-99, ea);
+            if (M->m.is_aligned) b_a *= p->psi * 3; /* :238-241 */
             rng_event(g);
             int in_donor = rng_uniform(g, 0) < b_d / (b_d + b_a);
             fret_event(s, p, g, in_donor, 1);

@@ -58,6 +58,7 @@ class Material(C.Structure):
                 ("align_S", C.c_double), ("abs_em_angle", C.c_double),
                 ("ol_DA", C.c_double), ("ol_AD", C.c_double),
                 ("P_ET_DA", C.c_double), ("P_ET_AD", C.c_double),
+                ("psi_P", C.c_double), ("psi_Q", C.c_double), ("align_frame", c_double9),
                 ("abs_A", Table), ("abs_D", Table), ("em_A", Table), ("em_D", Table)]
 
 

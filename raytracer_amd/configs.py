@@ -79,7 +79,8 @@ SUN = "Sun spectrum AG15g"
 
 
 def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=False,
-             aligned=False, align_s=0.1):
+             aligned=False, align_s=0.1, abs_em_angle=0, respect_pol=True,
+             direction=(0.0, 0.0, -1.0)):
     """One 5 x 5 cm dye-doped slab, source at (0, 2, 1) pointing down at 460 nm.
 
     thickness 0.012 + enclosed False is the shipped job's geometry."""
@@ -91,9 +92,9 @@ def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=Fal
         els, props, sizes = els + e2, props + p2, sizes + s2
     mats = [copy.deepcopy(AIR_ROW),
             dye_row(name, conc_a=1.0, conc_b=1.0 if donor else 0.0, aligned=aligned,
-                    align_s=align_s)]
+                    align_s=align_s, abs_em_angle=abs_em_angle)]
     photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460,
-                     "air", (0.0, 0.0, -1.0))
+                     "air", direction, respect_pol=respect_pol)
     return {
         "Elements": np.array(els, dtype=np.float64),
         "ElementProperties": props,
@@ -149,6 +150,15 @@ CONFIGS = {
     "C3": (slab_job, dict(thickness=0.3, enclosed=True, donor=True)),
     "C4": (stacked_job, dict()),
     "C5": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, sun=True)),
+    # aligned acceptor dyes: the shipped job's style (order parameter below the
+    # reference's 1e-10 threshold, dipoles along z; oblique incidence, because at
+    # normal incidence the field has no z component and nothing is absorbed) ...
+    "C6": (slab_job, dict(thickness=0.3, enclosed=True, aligned=True, align_s=1e-99,
+                          direction=(0.6, 0.0, -1.0))),
+    # ... and a finite order parameter with an absorption/emission dipole angle,
+    # donor present, emission polarisation not tied to the dipole
+    "C7": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, aligned=True, align_s=0.3,
+                          abs_em_angle=10, respect_pol=False)),
 }
 
 

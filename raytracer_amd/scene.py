@@ -54,6 +54,38 @@ def collect_materials(optical_elements, photon, material_dict=None):
     return mats
 
 
+def orientation_special_values(S):
+    """The six special-function values LambertBeerFullIntegral evaluates for
+    an order parameter S (reference PhotonObject.py:273): erf(a -/+ i b1),
+    erfi(b1), erf(a -/+ i b2), erfi(b2) with a = 2.2214.../S, b1 = S/sqrt(2),
+    b2 = 3 S/sqrt(2).  scipy.special is the library the reference itself calls."""
+    from scipy import special
+    a = 2.221441469079183 / S
+    b1, b2 = 0.7071067811865475 * S, 2.1213203435596424 * S
+    return (special.erf(a - 1j * b1), special.erf(a + 1j * b1), special.erfi(b1),
+            special.erf(a - 1j * b2), special.erf(a + 1j * b2), special.erfi(b2))
+
+
+def orientation_integral_constants(S):
+    """(P, Q) with LambertBeerFullIntegral(n) = |P (x^2 + y^2) + Q z^2|.
+
+    The reference's expression (PhotonObject.py:273) is linear in x^2 + y^2 and
+    z^2; because erf(conj z) = conj erf(z) the imaginary prefactors multiply
+    purely imaginary differences and both coefficients are real."""
+    if not S > 1e-10:                      # PhotonObject.py:272-276: ol = z^2
+        return 0.0, 1.0
+    import numpy as np_
+    em1, ep1, ei1, em2, ep2, ei2 = orientation_special_values(S)
+    c1, c2 = 0.2349964007466563j, 0.07833213358221876j
+    e1, e2 = np_.exp(-0.5 * S), np_.exp(-4.5 * S ** 2)
+    P = (e1 * (-c1 * em1 + c1 * ep1 + 0.4699928014933126 * ei1)
+         + e2 * (c2 * em2 - c2 * ep2 - 0.15666426716443752 * ei2)) / S
+    Q = (e1 * ((2 / 3.0) * (-c1 * em1 + c1 * ep1) + 0.313328534328875 * ei1)
+         + e2 * (-2 * (c2 * em2 - c2 * ep2) + 0.31332853432887503 * ei2)) / S
+    assert abs(P.imag) < 1e-12 * max(1.0, abs(P)) and abs(Q.imag) < 1e-12 * max(1.0, abs(Q))
+    return float(P.real), float(Q.real)
+
+
 def pack_material(m, name_ids, pool):
     out = _abi.Material()
     out.name_id = name_ids.setdefault(m.name, len(name_ids))
@@ -71,6 +103,9 @@ def pack_material(m, name_ids, pool):
     out.align_vect = _abi.c_double3(*av)
     out.align_S = float(m.AlignS)
     out.abs_em_angle = float(m.AbsEmAngle)
+    if m.IsAbsorber and m.IsAligned:
+        out.psi_P, out.psi_Q = orientation_integral_constants(float(m.AlignS))
+        out.align_frame = _abi.c_double9(*RTU.z_axis_frame(av).reshape(-1))
     if m.IsAbsorber:
         out.ol_DA, out.ol_AD = float(m.ol_DA), float(m.ol_AD)
         if m.conc_a > 0:
