@@ -200,6 +200,10 @@ typedef struct rtmc_photon_soa {
     double *start_wavelength;
     double *dist_left;      /* DistanceLeftToAbsorption                   */
     double *hit_distance;   /* out: SmallestDistance of the last iteration */
+    double *psi;            /* Photon.Psi: orientation integral of the last
+                               free-path draw in an aligned medium
+                               (PhotonObject.py:299), used again by the
+                               donor/acceptor coin (PhotonObject.py:241)  */
     int32_t *material;
     int32_t *status;        /* RTMC_ST_*                                  */
     int32_t *last_element;  /* RayTrace.FirstEl as an index, -1 = none    */

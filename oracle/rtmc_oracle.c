@@ -1032,6 +1032,7 @@ static void soa_load(const rtmc_photon_soa *b, uint32_t k, ph_t *p, const orc_sc
         p->old_point[j] = b->old_point[j][k];
     }
     p->wl = b->wavelength[k]; p->wl0 = b->start_wavelength[k]; p->dist_left = b->dist_left[k];
+    p->psi = b->psi[k];
     p->mat = b->material[k]; p->status = b->status[k];
     p->first_el = p->old_el = b->last_element[k];
     p->was_element = b->was_element[k]; p->reflected = b->reflected[k];
@@ -1050,6 +1051,7 @@ static void soa_store(rtmc_photon_soa *b, uint32_t k, const ph_t *p, const rng_t
     }
     b->wavelength[k] = p->wl; b->start_wavelength[k] = p->wl0; b->dist_left[k] = p->dist_left;
     b->hit_distance[k] = p->smallest;
+    b->psi[k] = p->psi;
     b->material[k] = p->mat; b->status[k] = p->status; b->last_element[k] = p->old_el;
     b->was_element[k] = p->was_element; b->reflected[k] = p->reflected; b->iterations[k] = p->iter;
     b->tape_pos[k] = (int32_t)(g->pos - tape_base);

@@ -99,7 +99,7 @@ class PhotonSoA(C.Structure):
     _fields_ = [("loc", _f64p * 3), ("dir", _f64p * 3), ("efield", _f64p * 3),
                 ("old_point", _f64p * 3),
                 ("wavelength", _f64p), ("start_wavelength", _f64p), ("dist_left", _f64p),
-                ("hit_distance", _f64p),
+                ("hit_distance", _f64p), ("psi", _f64p),
                 ("material", _i32p), ("status", _i32p), ("last_element", _i32p),
                 ("was_element", _i32p), ("reflected", _i32p), ("iterations", _i32p),
                 ("tape_pos", _i32p)]

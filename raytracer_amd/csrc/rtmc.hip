@@ -65,6 +65,7 @@ __device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char 
     Lds<real> l;
     l.elems = reinterpret_cast<const DevElem<real> *>(smem + sc.lay.elems);
     l.mats = reinterpret_cast<const DevMat<real> *>(smem + sc.lay.mats);
+    l.orient = reinterpret_cast<const DevOrient<real> *>(smem + sc.lay.orient);
     l.abs = reinterpret_cast<const DevAbs<real> *>(smem + sc.lay.abs);
     l.cdf = reinterpret_cast<const uint32_t *>(smem + sc.lay.cdf);
     l.fx = reinterpret_cast<const uint32_t *>(smem + sc.lay.fx);
@@ -90,7 +91,7 @@ enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
 #ifndef RTMC_TRACE_WAVES
 #define RTMC_TRACE_WAVES 1
 #endif
-template <typename real>
+template <typename real, bool ALIGNED>
 __global__ void __launch_bounds__(TRACE_BLOCK, RTMC_TRACE_WAVES)
 trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
              unsigned long long *work)
@@ -124,7 +125,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 const DevMat<real> &m = lds.mats[p.mat];
                 const DevAbs<real> &a = lds.abs[m.abs_slot * hot.n_wid + p.wid];
                 g.event();
-                const bool in_donor = g.u32(0) < a.coinT;
+                const bool in_donor = absorbed_by_donor<ALIGNED>(m, a, p, g);
                 uint32_t v_lambda;
                 const int outcome = fret_decide(m, g, in_donor, v_lambda);
                 if (outcome == 1) {
@@ -172,8 +173,15 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             // (c) one event for both: direction, polarisation, free path / wavelength
             if (launching | emitting) {
                 g.event();
-                if (launching) renew_launch(sc, lds, p, g);
-                else renew_emit(hot, lds, lds.mats[p.mat], p, g);
+                if (launching) {
+                    renew_launch(sc, lds, p, g);
+                } else {
+                    const DevMat<real> &m = lds.mats[p.mat];
+                    if (ALIGNED && (m.flags & 2) && p.status == RTMC_ST_REEMITTED_ACCEPTOR)
+                        renew_emit_aligned(hot, lds, m, p, g);
+                    else
+                        renew_emit<ALIGNED>(hot, lds, m, p, g);
+                }
                 need = NEED_NONE;
             }
         }
@@ -182,7 +190,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             continue;
         }
         if (need == NEED_NONE) {
-            const StepResult r = photon_step(hot, lds, p, g, tally);
+            const StepResult r = photon_step<ALIGNED>(hot, lds, p, g, tally);
             if (r == STEP_ENDED) {
                 count_fate(p, tally);
                 need = NEED_LAUNCH;
@@ -216,7 +224,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
 // device view of an rtmc_photon_soa batch (wavelengths already mapped to ids)
 struct SoaDev {
     double *loc[3], *dir[3], *efield[3], *old_point[3];
-    double *dist_left, *hit_distance;
+    double *dist_left, *hit_distance, *psi;
     int32_t *wid, *wid0, *material, *status, *last_element, *was_element, *reflected, *iterations,
         *tape_pos;
 };
@@ -247,6 +255,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
         p.Ex = real(b.efield[0][k]); p.Ey = real(b.efield[1][k]); p.Ez = real(b.efield[2][k]);
         p.oldx = real(b.old_point[0][k]); p.oldy = real(b.old_point[1][k]); p.oldz = real(b.old_point[2][k]);
         p.dist = real(b.dist_left[k]);
+        p.psi = real(b.psi[k]);
         p.hitd = M<real>::inf();
         p.wid = b.wid[k]; p.wid0 = b.wid0[k];
         p.mat = b.material[k]; p.status = b.status[k]; p.last_el = b.last_element[k];
@@ -265,7 +274,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
                    p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
     for (uint32_t it = 0; it < n_steps && alive; it++) {
-        StepResult r = photon_step(hot, lds, p, g, tally);
+        StepResult r = photon_step<true>(hot, lds, p, g, tally);
         if (r == STEP_ABSORBED) {
             emit_in_reference_order(hot, lds, p, g);
             r = finish_absorbed_iteration(hot, p);
@@ -284,7 +293,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     b.dir[0][k] = p.Dx; b.dir[1][k] = p.Dy; b.dir[2][k] = p.Dz;
     b.efield[0][k] = p.Ex; b.efield[1][k] = p.Ey; b.efield[2][k] = p.Ez;
     b.old_point[0][k] = p.oldx; b.old_point[1][k] = p.oldy; b.old_point[2][k] = p.oldz;
-    b.dist_left[k] = p.dist; b.hit_distance[k] = p.hitd;
+    b.dist_left[k] = p.dist; b.hit_distance[k] = p.hitd; b.psi[k] = p.psi;
     b.wid[k] = p.wid; b.wid0[k] = p.wid0; b.material[k] = p.mat; b.status[k] = p.status;
     b.last_element[k] = p.last_el; b.was_element[k] = (p.flags & F_WAS_EL) != 0u; b.reflected[k] = (p.flags & F_REFLECTED) != 0u;
     b.iterations[k] = p.iter; b.tape_pos[k] = (int32_t)g.pos;
@@ -415,6 +424,7 @@ struct PerDevice {
 
 struct rtmc_scene {
     int n_el = 0, n_mat = 0, n_eqe = 0, max_iter = 0;
+    bool has_aligned = false;       // some medium has aligned acceptor dyes: the kernels with that code are used
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
@@ -522,7 +532,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         DevMat<real> &o = mats[i];
         memset(&o, 0, sizeof o);
         o.n = (real)m.n;
-        o.flags = m.is_absorber ? 1 : 0;
+        o.flags = (m.is_absorber ? 1 : 0) | (m.is_absorber && m.is_aligned ? 2 : 0);
         o.name_id = m.name_id;
         o.abs_slot = mat_abs_slot[i];
         if (!m.is_absorber) continue;
@@ -549,6 +559,20 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.widD_off = cdf_wid_off[mat_cdfD[i]];
         o.cdfA_off = cdf_off[mat_cdfA[i]]; o.cdfA_len = (int)cdfs[mat_cdfA[i]].size();
         o.widA_off = cdf_wid_off[mat_cdfA[i]];
+    }
+    // aligned acceptors: PhotonObject.py:291-302, MonteCarloFRET.py:124-157
+    std::vector<DevOrient<real>> orient(n_mat);
+    for (int i = 0; i < n_mat; i++) {
+        const rtmc_material &m = d->materials[i];
+        DevOrient<real> &o = orient[i];
+        memset(&o, 0, sizeof o);
+        if (!(m.is_absorber && m.is_aligned)) continue;
+        o.P = (real)m.psi_P; o.Q = (real)m.psi_Q;
+        for (int j = 0; j < 9; j++) o.f[j] = (real)m.align_frame[j];
+        o.S = (real)m.align_S;
+        const double th = (m.abs_em_angle / 180.0) * 3.141592653589793;  // MonteCarloFRET.py:140
+        o.sin_ae = (real)std::sin(th); o.cos_ae = (real)std::cos(th);
+        o.flags = (d->source.respect_polarization ? 1 : 0) | (m.abs_em_angle > 0 ? 2 : 0);
     }
     std::vector<DevAbs<real>> abs((size_t)n_slots * n_wid);
     const double ln10 = std::log(10.0);
@@ -577,6 +601,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     size_t off = 0;
     lay.elems = (uint32_t)off; off = align(off + sizeof(DevElem<real>) * std::max(1, n_el));
     lay.mats = (uint32_t)off; off = align(off + sizeof(DevMat<real>) * std::max(1, n_mat));
+    lay.orient = (uint32_t)off; off = align(off + sizeof(DevOrient<real>) * std::max(1, n_mat));
     lay.abs = (uint32_t)off; off = align(off + sizeof(DevAbs<real>) * std::max<size_t>(1, abs.size()));
     lay.cdf = (uint32_t)off; off = align(off + 4 * cdfT.size());
     lay.fx = (uint32_t)off; off = align(off + 4 * energy_fx.size());
@@ -591,6 +616,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     img.lds.assign(off, 0);
     if (n_el) memcpy(img.lds.data() + lay.elems, img.elems.data(), sizeof(DevElem<real>) * n_el);
     if (n_mat) memcpy(img.lds.data() + lay.mats, mats.data(), sizeof(DevMat<real>) * n_mat);
+    if (n_mat) memcpy(img.lds.data() + lay.orient, orient.data(), sizeof(DevOrient<real>) * n_mat);
     if (!abs.empty()) memcpy(img.lds.data() + lay.abs, abs.data(), sizeof(DevAbs<real>) * abs.size());
     memcpy(img.lds.data() + lay.cdf, cdfT.data(), 4 * cdfT.size());
     memcpy(img.lds.data() + lay.fx, energy_fx.data(), 4 * energy_fx.size());
@@ -663,6 +689,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     std::vector<int> em_kind;        // 0 emission, 1 source spectrum
     std::vector<int> mat_cdfD(d->n_materials, -1), mat_cdfA(d->n_materials, -1), mat_abs_slot(d->n_materials, -1);
     int src_cdf = -1, n_slots = 0;
+    bool has_aligned = false;
     std::vector<double> wl;
     std::vector<int> cdf_wid_off;
 
@@ -689,7 +716,13 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     for (int i = 0; i < d->n_materials; i++) {
         const rtmc_material &m = d->materials[i];
         if (!m.is_absorber) continue;
-        if (m.is_aligned) return fail(RTMC_EUNSUPPORTED, "material %d: aligned dyes are not built so far", i);
+        if (m.is_aligned) {
+            double f2 = 0;
+            for (int j = 0; j < 9; j++) f2 += m.align_frame[j] * m.align_frame[j];
+            if (!(f2 > 0) || !std::isfinite(f2) || !std::isfinite(m.psi_P) || !std::isfinite(m.psi_Q) || !(m.align_S >= 0))
+                return fail(RTMC_EINVAL, "material %d: aligned dyes need align_frame, psi_P, psi_Q and a non-negative align_S", i);
+            has_aligned = true;
+        }
         int rc;
         HostTable eD, eA;
         if ((rc = get_table(d, m.abs_A, absA[i], "abs_A")) || (rc = get_table(d, m.abs_D, absD[i], "abs_D")) ||
@@ -712,6 +745,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
 
     rtmc_scene *s = new rtmc_scene;
     s->n_el = d->n_elements; s->n_mat = d->n_materials; s->n_eqe = d->n_tables; s->max_iter = d->max_iterations;
+    s->has_aligned = has_aligned;
     s->elements.assign(d->elements, d->elements + d->n_elements);
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
@@ -841,13 +875,15 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     p.n_cu = prop.multiProcessorCount;
-    HIP_TRY(hipFuncSetAttribute((const void *)trace_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
+    const void *trace32 = s->has_aligned ? (const void *)trace_kernel<float, true> : (const void *)trace_kernel<float, false>;
+    const void *trace64 = s->has_aligned ? (const void *)trace_kernel<double, true> : (const void *)trace_kernel<double, false>;
+    HIP_TRY(hipFuncSetAttribute(trace32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
     HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks32, trace_kernel<float>, TRACE_BLOCK, s->img32.lay.total));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks32, trace32, TRACE_BLOCK, s->img32.lay.total));
     if (s->img64.lay.total <= 160 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)trace_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
+        HIP_TRY(hipFuncSetAttribute(trace64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
         HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace_kernel<double>, TRACE_BLOCK, s->img64.lay.total));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace64, TRACE_BLOCK, s->img64.lay.total));
     }
     {
         int rc = upload_scene_structs(s, p);
@@ -923,11 +959,17 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
     HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
-    if (f32)
-        hipLaunchKernelGGL(trace_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+    if (f32 && !s->has_aligned)
+        hipLaunchKernelGGL((trace_kernel<float, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
                            (const DevScene<float> *)p.scene32, tl, seed, first_photon, n_photons, p.work);
+    else if (f32)
+        hipLaunchKernelGGL((trace_kernel<float, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                           (const DevScene<float> *)p.scene32, tl, seed, first_photon, n_photons, p.work);
+    else if (!s->has_aligned)
+        hipLaunchKernelGGL((trace_kernel<double, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                           (const DevScene<double> *)p.scene64, tl, seed, first_photon, n_photons, p.work);
     else
-        hipLaunchKernelGGL(trace_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+        hipLaunchKernelGGL((trace_kernel<double, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
                            (const DevScene<double> *)p.scene64, tl, seed, first_photon, n_photons, p.work);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p.ev1, p.stream));
@@ -1020,7 +1062,7 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
             if (b->tape_pos[k] < 0 || (uint64_t)b->tape_pos[k] > seg) return fail(RTMC_EINVAL, "photon %u: tape position outside its segment", k);
         }
     }
-    const size_t nd = 14, ni = 9;  // double / int32 columns
+    const size_t nd = 15, ni = 9;  // double / int32 columns
     const size_t tape_len = tape_off[n];
     DeviceBuffer dbuf, ibuf, tbuf, obuf, trbuf, ovbuf;
     HIP_TRY(hipMalloc(&dbuf.ptr, 8 * nd * n));
@@ -1041,6 +1083,7 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
     }
     sd.dist_left = dd + (size_t)12 * n; hsrc[12] = b->dist_left;
     sd.hit_distance = dd + (size_t)13 * n; hsrc[13] = b->hit_distance;
+    sd.psi = dd + (size_t)14 * n; hsrc[14] = b->psi;
     int32_t *icols[ni];
     for (size_t j = 0; j < ni; j++) icols[j] = ii + j * n;
     sd.wid = icols[0]; sd.wid0 = icols[1]; sd.material = icols[2]; sd.status = icols[3];
@@ -1069,7 +1112,7 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
     // results
     double *hdst[nd];
     for (int j = 0; j < 3; j++) { hdst[j] = b->loc[j]; hdst[3 + j] = b->dir[j]; hdst[6 + j] = b->efield[j]; hdst[9 + j] = b->old_point[j]; }
-    hdst[12] = b->dist_left; hdst[13] = b->hit_distance;
+    hdst[12] = b->dist_left; hdst[13] = b->hit_distance; hdst[14] = b->psi;
     for (size_t j = 0; j < nd; j++) HIP_TRY(hipMemcpyAsync(hdst[j], dd + j * n, 8 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
     int32_t *idst[ni] = {wid.data(), wid0.data(), b->material, b->status, b->last_element,
                          b->was_element, b->reflected, b->iterations, b->tape_pos};

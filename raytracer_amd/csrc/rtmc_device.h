@@ -74,7 +74,7 @@ struct alignas(64) HitChunk {
 template <typename real>
 struct DevMat {
     real n;
-    int32_t flags;     // bit 0: absorber
+    int32_t flags;     // bit 0: absorber, bit 1: its acceptor dyes are aligned
     int32_t name_id;
     int32_t abs_slot;  // row block in the absorption table, -1 if not an absorber
     int32_t n_p;       // 3: donor pathways incl. transfer, 2: no acceptor present
@@ -93,6 +93,18 @@ struct DevAbs {
     uint32_t coinT;  // ceil(b_d / (b_d + b_a) * 2^32): "absorbed by the donor" threshold
 };
 
+// Orientation data of a medium with aligned acceptor dyes (one record per
+// medium, zeros for the others).
+template <typename real>
+struct DevOrient {
+    real P, Q;            // orientation integral |P (x^2 + y^2) + Q z^2| of a unit field vector in the alignment frame
+    real f[9];            // alignment frame: columns n1, n2, AlignVect (row-major)
+    real S;               // width of the Gaussian tilt of the dipoles about AlignVect [rad]
+    real sin_ae, cos_ae;  // angle between absorption and emission dipole
+    int32_t flags;        // bit 0: emission polarised along the dipole, bit 1: sin_ae/cos_ae in use
+    int32_t pad;
+};
+
 template <typename real>
 struct DevSource {
     real loc[3];
@@ -105,7 +117,7 @@ struct DevSource {
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, abs, cdf, fx, bin, acc, hist, total;
+    uint32_t elems, mats, orient, abs, cdf, fx, bin, acc, hist, total;
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
@@ -169,6 +181,9 @@ template <> struct M<float> {
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float log(float x) { return ::logf(x); }
     static __device__ __forceinline__ void sincospi(float x, float *s, float *c) { ::sincospif(x, s, c); }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
+    static __device__ __forceinline__ float acos(float x) { return ::acosf(x); }
+    static __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
     // sin/cos of 2 pi x for x in [0, 1): v_sin_f32 / v_cos_f32 take their argument in turns
     static __device__ __forceinline__ void sincos_turns(float x, float *s, float *c)
     {
@@ -190,6 +205,9 @@ template <> struct M<double> {
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ void sincospi(double x, double *s, double *c) { ::sincospi(x, s, c); }
+    static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
+    static __device__ __forceinline__ double acos(double x) { return ::acos(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
     static __device__ __forceinline__ void sincos_turns(double x, double *s, double *c) { ::sincospi(2.0 * x, s, c); }
     static __device__ __forceinline__ double neg_log1m(double u) { return -::log(1.0 - u); }
     static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
@@ -276,6 +294,7 @@ struct Rng<real, true> {
     {
         a = real(next()); b = real(next()); c = real(next());
     }
+    __device__ __forceinline__ real normal1() { return real(next()); }
     // the reference draws a free path even for a photon that was just lost to
     // internal conversion (PhotonObject.py:250/258); the tape holds that value
     __device__ __forceinline__ bool consume_dead_draws() const { return true; }
@@ -288,6 +307,7 @@ template <typename real>
 struct Photon {
     real Lx, Ly, Lz, Dx, Dy, Dz, Ex, Ey, Ez;
     real dist;       // DistanceLeftToAbsorption
+    real psi;        // Photon.Psi (aligned media only; dead otherwise)
     real hitd;       // SmallestDistance of the last iteration
     real best_t;     // signed line parameter of the last candidate
     real oldx, oldy, oldz;  // RayTrace.OldPoint (read back by the step-wise interface only)
@@ -313,6 +333,7 @@ template <typename real>
 struct Lds {
     const DevElem<real> *elems;
     const DevMat<real> *mats;
+    const DevOrient<real> *orient;
     const DevAbs<real> *abs;
     const uint32_t *cdf;
     const uint32_t *fx;    // per wavelength id: llrint(wl_source / wl * 2^24) for a single-line source
@@ -339,13 +360,52 @@ __device__ __forceinline__ void normalize3(real &x, real &y, real &z)
     x *= s; y *= s; z *= s;
 }
 
-// PhotonObject.py:283-305 LamBeerDistance for an absorbing medium
+// PhotonObject.py:295-299 + 267-281: the orientation integral Psi of the
+// field vector E, taken in the frame whose z axis is the alignment vector.
 template <typename real>
-__device__ __forceinline__ real free_path(const DevAbs<real> &a, real e, real inv_scale)
+__device__ __forceinline__ real orientation_integral(const DevOrient<real> &o, real Ex, real Ey, real Ez)
 {
-    real b = a.b_a + a.b_d;
+    real x = Ex * o.f[0] + Ey * o.f[3] + Ez * o.f[6];  // E (row) times frame
+    real y = Ex * o.f[1] + Ey * o.f[4] + Ez * o.f[7];
+    real z = Ex * o.f[2] + Ey * o.f[5] + Ez * o.f[8];
+    real xy = x * x + y * y, zz = z * z;
+    real ol = M<real>::abs(o.P * xy + o.Q * zz) * M<real>::rcp(xy + zz);
+    return ol < real(1e-10) ? real(0) : ol;
+}
+
+// PhotonObject.py:283-305 LamBeerDistance for absorbing medium `mat` (its
+// absorption rows start at `slot`), `e` a unit exponential.  In a medium with
+// aligned acceptors the acceptor coefficient is weighted by 3 Psi and Psi is
+// kept on the photon (PhotonObject.py:291-302).
+template <bool ALIGNED, typename real>
+__device__ __forceinline__ real free_path(const HotScene<real> &sc, const Lds<real> &lds, int mat, int slot,
+                                          Photon<real> &p, real e)
+{
+    const DevAbs<real> &a = lds.abs[slot * sc.n_wid + p.wid];
+    real b_a = a.b_a;
+    if (ALIGNED) {
+        if (lds.mats[mat].flags & 2) {
+            p.psi = orientation_integral(lds.orient[mat], p.Ex, p.Ey, p.Ez);
+            b_a *= p.psi * real(3);
+        }
+    }
+    real b = b_a + a.b_d;
     real mfp = b > real(0) ? M<real>::rcp(b) : M<real>::huge();
-    return inv_scale * (mfp * e);
+    return sc.inv_scale * (mfp * e);
+}
+
+// PhotonObject.py:235-244: was the photon absorbed by the donor?  One uniform.
+template <bool ALIGNED, typename real, bool TAPE>
+__device__ __forceinline__ bool absorbed_by_donor(const DevMat<real> &m, const DevAbs<real> &a, const Photon<real> &p,
+                                                  Rng<real, TAPE> &g)
+{
+    if (ALIGNED) {
+        if (m.flags & 2) {  // PhotonObject.py:238-241
+            real b_a = a.b_a * (p.psi * real(3));
+            return g.uniform(0) < a.b_d / (a.b_d + b_a);  // 0/0 compares false: acceptor
+        }
+    }
+    return g.u32(0) < a.coinT;
 }
 
 // What the next nearest-hit search may accept, from the operation just
@@ -382,6 +442,7 @@ __device__ __forceinline__ void init_photon_common(SceneArg<real> sc, Photon<rea
     p.wid0 = p.wid;
     p.mat = sc.src.start_mat;
     p.dist = real(0);
+    p.psi = real(0);
     p.hitd = M<real>::inf();
     p.best_t = real(0);
     p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
@@ -476,6 +537,57 @@ __device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE
     }
 }
 
+// np.roll(MakeVectAxis(v), 2, axis=1) applied to a column vector
+// (RTUtils.py:25-42): the frame with columns n1 = unit(v x x^), n2 = unit(v x n1), v
+// (y^ takes the place of x^ when v is exactly x^).
+template <typename real>
+__device__ __forceinline__ void to_axis_frame(real vx, real vy, real vz, real &Dx, real &Dy, real &Dz)
+{
+    const bool is_x = (vx == real(1)) & (vy == real(0)) & (vz == real(0));
+    real ax = is_x ? -vz : real(0), ay = is_x ? real(0) : vz, az = is_x ? vx : -vy;
+    normalize3(ax, ay, az);
+    real bx = vy * az - vz * ay, by = vz * ax - vx * az, bz = vx * ay - vy * ax;
+    normalize3(bx, by, bz);
+    real x = ax * Dx + bx * Dy + vx * Dz;
+    real y = ay * Dx + by * Dy + vy * Dz;
+    real z = az * Dx + bz * Dy + vz * Dz;
+    Dx = x; Dy = y; Dz = z;
+}
+
+// MonteCarloFRET.py:124-157: fluorescence of an aligned acceptor from sampled
+// angles.  (sx, cx): polar angle of the emission about the dipole, law sin^3
+// (RTUtils.py:56-100); az: its azimuth; tilt, phi: polar angle and azimuth of
+// the dipole about the alignment vector (RTUtils.py:45-54); ph: azimuth of the
+// emission dipole about the absorption dipole (used if the medium has an
+// absorption/emission angle).  Azimuths arrive as (sin, cos) pairs.  Returns
+// false if the polarisation is still to be drawn (PhotonObject.py:107-114).
+template <typename real>
+__device__ __forceinline__ bool aligned_emission(const DevOrient<real> &o, real sx, real cx, real s_az, real c_az,
+                                                 real tilt, real s_phi, real c_phi, real s_ph, real c_ph,
+                                                 Photon<real> &p)
+{
+    real Dx = sx * c_az, Dy = sx * s_az, Dz = cx;  // RTUtils.py:97-100
+    real st, ct;
+    M<real>::sincos(tilt, &st, &ct);
+    const real mx = st * c_phi, my = st * s_phi, mz = ct;  // RTUtils.py:49
+    real vx = o.f[0] * mx + o.f[1] * my + o.f[2] * mz;     // RTUtils.py:51-53
+    real vy = o.f[3] * mx + o.f[4] * my + o.f[5] * mz;
+    real vz = o.f[6] * mx + o.f[7] * my + o.f[8] * mz;
+    normalize3(vx, vy, vz);
+    if (o.flags & 2)  // MonteCarloFRET.py:139-149
+        to_axis_frame(o.sin_ae * c_ph, o.sin_ae * s_ph, o.cos_ae, Dx, Dy, Dz);
+    to_axis_frame(vx, vy, vz, Dx, Dy, Dz);  // :151-152
+    normalize3(Dx, Dy, Dz);
+    p.Dx = Dx; p.Dy = Dy; p.Dz = Dz;
+    if (!(o.flags & 1)) return false;
+    // PhotonObject.py:100-105: E = unit(D x (dipole x D))
+    real ax = vy * Dz - vz * Dy, ay = vz * Dx - vx * Dz, az = vx * Dy - vy * Dx;
+    real ex = Dy * az - Dz * ay, ey = Dz * ax - Dx * az, ez = Dx * ay - Dy * ax;
+    normalize3(ex, ey, ez);
+    p.Ex = ex; p.Ey = ey; p.Ez = ez;
+    return true;
+}
+
 // PhotonObject.py:219-258 after the photon has been moved to the absorption
 // point: donor/acceptor coin, pathway, re-emission, new free path -- with the
 // draws in the reference's order.
@@ -485,10 +597,25 @@ __device__ __forceinline__ void emit_in_reference_order(const HotScene<real> &sc
 {
     const DevMat<real> &m = lds.mats[p.mat];
     const DevAbs<real> &a = lds.abs[m.abs_slot * sc.n_wid + p.wid];
-    bool in_donor = g.u32(0) < a.coinT;  // PhotonObject.py:244
+    bool in_donor = absorbed_by_donor<true>(m, a, p, g);  // PhotonObject.py:244
     uint32_t v_lambda;
     int outcome = fret_decide(m, g, in_donor, v_lambda);
-    if (outcome == 1) {  // direction, wavelength, polarisation (MonteCarloFRET.py:95-103)
+    if (outcome == 2 && (m.flags & 2)) {  // MonteCarloFRET.py:124-162
+        const DevOrient<real> &o = lds.orient[p.mat];
+        real sx, cx, s_az, c_az, s_phi, c_phi, s_ph = real(0), c_ph = real(1);
+        for (;;) {  // RTUtils.py:64-68 rejection sampling of sin^3 on [0, pi]
+            M<real>::sincospi(g.uniform(0), &sx, &cx);
+            const real uy = g.uniform(0);
+            if (!(uy > sx * sx * sx) || g.overrun) break;
+        }
+        M<real>::sincos_turns(g.uniform(0), &s_az, &c_az);  // RTUtils.py:96
+        const real tilt = o.S * g.normal1();                // RTUtils.py:47
+        M<real>::sincos_turns(g.uniform(0), &s_phi, &c_phi);
+        if (o.flags & 2) M<real>::sincos_turns(g.uniform(0), &s_ph, &c_ph);  // MonteCarloFRET.py:141
+        if (!aligned_emission(o, sx, cx, s_az, c_az, tilt, s_phi, c_phi, s_ph, c_ph, p)) random_polarization(p, g);
+        p.wid = m.widA_off + cdf_pick(lds.cdf + m.cdfA_off, m.cdfA_len, g.u32(3));
+        p.status = RTMC_ST_REEMITTED_ACCEPTOR;
+    } else if (outcome == 1) {  // direction, wavelength, polarisation (MonteCarloFRET.py:95-103)
         isotropic_direction(p, g);
         p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, g.u32(3));
         p.status = RTMC_ST_REEMITTED_DONOR;
@@ -502,7 +629,7 @@ __device__ __forceinline__ void emit_in_reference_order(const HotScene<real> &sc
         p.status = RTMC_ST_INTERNAL_CONVERTED;
     }
     // PhotonObject.py:250/258: a free path is drawn whatever happened
-    p.dist = free_path(lds.abs[m.abs_slot * sc.n_wid + p.wid], g.expo(0), sc.inv_scale);
+    p.dist = free_path<true>(sc, lds, p.mat, m.abs_slot, p, g.expo(0));
 }
 
 // ---------------------------------------------------------------------------
@@ -558,13 +685,42 @@ __device__ __forceinline__ void renew_launch(SceneArg<real> sc, const Lds<real> 
 
 // Re-emission (MonteCarloFRET.py:92-105,170-175 + PhotonObject.py:250/258)
 // with one event: words 0,1 direction, 2 polarisation angle, 3 free path.
-template <typename real>
+template <bool ALIGNED, typename real>
 __device__ __forceinline__ void renew_emit(const HotScene<real> &sc, const Lds<real> &lds, const DevMat<real> &m,
                                            Photon<real> &p, Rng<real, false> &g)
 {
     sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
     perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
-    p.dist = free_path(lds.abs[m.abs_slot * sc.n_wid + p.wid], g.expo(3), sc.inv_scale);
+    p.dist = free_path<ALIGNED>(sc, lds, p.mat, m.abs_slot, p, g.expo(3));
+}
+
+// Fluorescence of an aligned acceptor (MonteCarloFRET.py:124-162) with two
+// events.  The first (already opened by the caller): word 0 polar angle of the
+// emission about the dipole through the closed-form inverse of the sin^3
+// distribution function F(c) = (2 - 3c + c^3)/4, c = cos(angle) -- the reference
+// samples the same law by rejection (RTUtils.py:64-68) --, word 1 its azimuth,
+// words 2,3 the normal variate of the dipole tilt (Box-Muller).  The second:
+// word 0 tilt azimuth, 1 emission-dipole azimuth, 2 polarisation angle, 3 free path.
+template <typename real>
+__device__ __forceinline__ void renew_emit_aligned(const HotScene<real> &sc, const Lds<real> &lds,
+                                                   const DevMat<real> &m, Photon<real> &p, Rng<real, false> &g)
+{
+    const DevOrient<real> &o = lds.orient[p.mat];
+    const real pi = real(3.141592653589793);
+    const real cx = real(2) * M<real>::cos((M<real>::acos(real(2) * g.uniform(0) - real(1)) + real(4) * pi) * real(1.0 / 3.0));
+    const real s2 = real(1) - cx * cx;
+    const real sx = M<real>::sqrt(s2 > real(0) ? s2 : real(0));
+    real s_az, c_az, s_g, c_g, s_phi, c_phi, s_ph, c_ph;
+    M<real>::sincos_turns(g.uniform(1), &s_az, &c_az);
+    const real r = M<real>::sqrt(real(-2) * M<real>::log((real(g.w[2] >> 8) + real(1)) * real(1.0 / 16777216.0)));
+    M<real>::sincos_turns(g.uniform(3), &s_g, &c_g);
+    const real tilt = o.S * (r * c_g);
+    g.event();
+    M<real>::sincos_turns(g.uniform(0), &s_phi, &c_phi);
+    M<real>::sincos_turns(g.uniform(1), &s_ph, &c_ph);
+    if (!aligned_emission(o, sx, cx, s_az, c_az, tilt, s_phi, c_phi, s_ph, c_ph, p))
+        perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
+    p.dist = free_path<true>(sc, lds, p.mat, m.abs_slot, p, g.expo(3));
 }
 
 // ---------------------------------------------------------------------------
@@ -701,7 +857,7 @@ enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 // absorbed photon needs its pathway drawn: the caller does that
 // (emit_in_reference_order / the renew block of the trace kernel) and then
 // calls finish_absorbed_iteration.
-template <typename real, bool TAPE, typename Tally>
+template <bool ALIGNED, typename real, bool TAPE, typename Tally>
 __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, const Lds<real> &lds,
                                                   Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
 {
@@ -859,8 +1015,8 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
                     p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
                     p.mat = other;
                     p.flags &= ~F_REFLECTED;
-                    if (other_slot >= 0)
-                        p.dist = free_path(lds.abs[other_slot * sc.n_wid + p.wid], g.expo(1), sc.inv_scale);
+                    if (other_slot >= 0)  // PhotonObject.py:283-305, with E as Reflectance left it
+                        p.dist = free_path<ALIGNED>(sc, lds, other, other_slot, p, g.expo(1));
                     else
                         p.dist = real(0);
                 }

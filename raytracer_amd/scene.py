@@ -236,7 +236,7 @@ def tallies_to_dict(t, arrays):
 
 
 SOA_VEC = ["loc", "dir", "efield", "old_point"]
-SOA_F64 = ["wavelength", "start_wavelength", "dist_left", "hit_distance"]
+SOA_F64 = ["wavelength", "start_wavelength", "dist_left", "hit_distance", "psi"]
 SOA_I32 = ["material", "status", "last_element", "was_element", "reflected", "iterations",
            "tape_pos"]
 

@@ -46,7 +46,7 @@ def test_f64_tape_replay_matches_reference(scenes, name):
     assert len(bad) <= allowed, "photons off the reference path: %s (worst %.2e)" % (bad[:10], worst)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
 def test_f32_tape_replay_follows_reference(scenes, name):
     """float32 kernels on the reference's variates: same discrete path for
     (nearly) every photon and vectors within 2e-5 after a whole trajectory
@@ -72,7 +72,7 @@ def _oracle_states(oracle_mod, rt, g, max_iter):
     return states
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
 def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     """One loop iteration from identical input state and identical variates:
     float32 positions, directions, polarisation and free path agree with the
@@ -148,7 +148,7 @@ def _sigma(n, p):
     return max(1.0, (n * p * (1 - p)) ** 0.5)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
 def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     """Same seed, same Philox stream, float64 on both sides: every integer
     tally is identical except for the odd photon that passes within rounding
@@ -170,7 +170,7 @@ def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     assert np.abs(gpu["energy_fx"].astype(np.int64) - cpu["energy_fx"].astype(np.int64)).max() <= 8 << 24
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
 def test_f32_follows_f64_photon_for_photon(scenes, name):
     """float32 production kernels against the float64 instantiation on the
     same 5e6 photons: a photon changes fate only when it passes within
@@ -185,7 +185,7 @@ def test_f32_follows_f64_photon_for_photon(scenes, name):
     assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= n // 2000
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C1_open"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C1_open"])
 def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     """Production path against the reference's own seeded runs
     (tests/golden/ref_tallies.json): every detector count, internal
