@@ -156,7 +156,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          "traffic": measured_traffic(args.config, per_step),
-                         "kernel": "trace_kernel<float>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "kernel": "trace_kernel<float, 0>", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "flop_per_iteration": flops_per_iteration(n_el),
                          "iterations_per_launch": iters_per_launch,
                          "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": PEAK_HBM_GBS,

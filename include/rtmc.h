@@ -65,7 +65,14 @@ extern "C" {
 /* One optical element = reference OpticalObject(Type, Geometry).
  * Rectangle: Geometries.py:8-57.  `e1`/`e2` are the unit in-plane axes the
  * reference derives in the constructor (Geometries.py:17-29, normalised at
- * :40-41); `half1` pairs with e1 ("Height"), `half2` with e2 ("Width"). */
+ * :40-41); `half1` pairs with e1 ("Height"), `half2` with e2 ("Width").
+ * Circle (Geometries.py:60-86): support, unit normal, half1 = Radius.
+ * Cylinder (Geometries.py:90-209): `support` and `normal` hold the two end
+ * points of the axis as the reference's constructor receives them
+ * (SupportVector, DirectionVector), half1 = Radius; the wall has no caps.
+ * Triangle (Geometries.py:212-255): e1, e2, vertex3 = the three corners;
+ * support = their centroid, normal = unit((e2 - e1) x (vertex3 - e1))
+ * (RTUtils.py:126-133). */
 typedef struct rtmc_element {
     int32_t geometry;   /* RTMC_GEOM_*                                     */
     int32_t type;       /* RTMC_TYPE_*                                     */
@@ -81,6 +88,7 @@ typedef struct rtmc_element {
                            spectrum (Elements.py:161-165), or -1           */
     int32_t reserved;
     double focal_length; /* Lens (Elements.py:117-132)                     */
+    double vertex3[3];   /* Triangle: third corner                         */
 } rtmc_element;
 
 /* A two-column table (wavelength, value) stored as 2*len doubles,

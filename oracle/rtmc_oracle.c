@@ -245,9 +245,9 @@ ORC_EXPORT int orc_scene_create(const rtmc_scene_desc *d, orc_scene **out)
     s->max_iter = d->max_iterations;
     for (int i = 0; i < s->n_el; i++) {
         const rtmc_element *e = &s->el[i];
-        if (e->geometry != RTMC_GEOM_RECTANGLE ||
-            (e->type != RTMC_TYPE_MIRROR && e->type != RTMC_TYPE_INTERFACE && e->type != RTMC_TYPE_DUMP)) {
-            snprintf(g_err, sizeof g_err, "element %d: geometry %d / type %d not restated yet", i, e->geometry, e->type);
+        if (e->geometry < RTMC_GEOM_RECTANGLE || e->geometry > RTMC_GEOM_TRIANGLE ||
+            e->type < RTMC_TYPE_MIRROR || e->type > RTMC_TYPE_DUMP) {
+            snprintf(g_err, sizeof g_err, "element %d: unknown geometry %d / type %d", i, e->geometry, e->type);
             orc_scene_destroy(s);
             return RTMC_EUNSUPPORTED;
         }
@@ -559,6 +559,153 @@ static int rect_intersect(const rtmc_element *e, const double *L, const double *
     return 0;
 }
 
+/* line-plane intersection shared by the flat shapes:
+ * B = ((S - L).n / (D.n)) D + L, Geometries.py:38,72,223 */
+static int plane_point(const rtmc_element *e, const double *L, const double *D, double *B)
+{
+    double dn = dot3(D, e->normal);
+    if (dn == 0) return 0;
+    double sl[3] = {e->support[0] - L[0], e->support[1] - L[1], e->support[2] - L[2]};
+    double t = dot3(sl, e->normal) / dn;
+    for (int j = 0; j < 3; j++) B[j] = t * D[j] + L[j];
+    return 1;
+}
+
+/* Geometries.py:68-80 Circle.FindIntersections */
+static int circle_intersect(const rtmc_element *e, const double *L, const double *D, double *B)
+{
+    if (!plane_point(e, L, D, B)) return 0;
+    double d[3] = {B[0] - e->support[0], B[1] - e->support[1], B[2] - e->support[2]};
+    return !(e->half1 < norm3(d));
+}
+
+/* RTUtils.py:25-42 MakeVectAxis: columns v, n1, n2 */
+static void vect_axis(const double *v, double *n1, double *n2)
+{
+    double nv[3] = {1, 0, 0};
+    if (v[0] == 1 && v[1] == 0 && v[2] == 0) { nv[0] = 0; nv[1] = 1; }
+    cross3(v, nv, n1);
+    double n = norm3(n1);
+    n1[0] /= n; n1[1] /= n; n1[2] /= n;
+    cross3(v, n1, n2);
+    n = norm3(n2);
+    n2[0] /= n; n2[1] /= n; n2[2] /= n;
+}
+
+/* Geometries.py:220-251 Triangle.FindIntersections / CheckPointInTriangle:
+ * e1, e2, vertex3 are the three corners */
+static int triangle_intersect(const rtmc_element *e, const double *L, const double *D, double *B)
+{
+    if (!plane_point(e, L, D, B)) return 0;
+    double n1[3], n2[3];
+    vect_axis(e->normal, n1, n2); /* transpose(tm) rows: normal, n1, n2; only rows 1, 2 are used */
+    const double *c[3] = {e->e1, e->e2, e->vertex3};
+    double q[3][2], pt[2] = {dot3(n1, B), dot3(n2, B)};
+    for (int i = 0; i < 3; i++) { q[i][0] = dot3(n1, c[i]); q[i][1] = dot3(n2, c[i]); }
+#define SCL(p1, p2, p3) (((p1)[0] - (p3)[0]) * ((p2)[1] - (p3)[1]) - ((p2)[0] - (p3)[0]) * ((p1)[1] - (p3)[1]))
+    int b1 = SCL(pt, q[0], q[1]) < 0.0;
+    int b2 = SCL(pt, q[1], q[2]) < 0.0;
+    int b3 = SCL(pt, q[2], q[0]) < 0.0;
+#undef SCL
+    return b1 == b2 && b2 == b3;
+}
+
+/* Geometries.py:156-204 IntersectLineCylinder: support/normal hold the two axis
+ * end points.  ok1/ok2 tell which of the two line points exist. */
+static void cylinder_line(const rtmc_element *e, const double *L, const double *D, double *p1, int *ok1,
+                          double *p2, int *ok2)
+{
+    *ok1 = *ok2 = 0;
+    double r = e->half1;
+    double a[3] = {e->support[0] - e->normal[0], e->support[1] - e->normal[1], e->support[2] - e->normal[2]};
+    double na = norm3(a);
+    a[0] /= na; a[1] /= na; a[2] /= na;
+    double n1[3], n2[3];
+    vect_axis(a, n1, n2); /* tm = transpose(MakeVectAxis(a)): rows a, n1, n2; its inverse has them as columns */
+    double ts[3] = {dot3(a, L), dot3(n1, L), dot3(n2, L)};
+    double td[3] = {dot3(a, D), dot3(n1, D), dot3(n2, D)};
+    double c1[3] = {dot3(a, e->support), dot3(n1, e->support), dot3(n2, e->support)};
+    double c2x = dot3(a, e->normal);
+    double a1 = td[1] * td[1] + td[2] * td[2];
+    double a2 = 2 * (td[1] * (ts[1] - c1[1]) + td[2] * (ts[2] - c1[2]));
+    double a3 = (ts[1] - c1[1]) * (ts[1] - c1[1]) + (ts[2] - c1[2]) * (ts[2] - c1[2]) - r * r;
+    double dsc = a2 * a2 - 4 * a1 * a3;
+    if (a1 == 0.0 || !(dsc >= 0)) return;
+    double t1 = (-a2 + sqrt(dsc)) / (2 * a1), t2 = (-a2 - sqrt(dsc)) / (2 * a1);
+    double lo = fmin(c1[0], c2x), hi = fmax(c1[0], c2x);
+    double v1[3], v2[3];
+    for (int j = 0; j < 3; j++) { v1[j] = ts[j] + t1 * td[j]; v2[j] = ts[j] + t2 * td[j]; }
+    for (int j = 0; j < 3; j++) {
+        p1[j] = fma(n2[j], v1[2], fma(n1[j], v1[1], a[j] * v1[0]));
+        p2[j] = fma(n2[j], v2[2], fma(n1[j], v2[1], a[j] * v2[0]));
+    }
+    *ok1 = !(v1[0] < lo || v1[0] > hi);
+    *ok2 = !(v2[0] < lo || v2[0] > hi);
+}
+
+/* Geometries.py:97-136 Cylinder.FindIntersections.  Returns 0 for "no point";
+ * the one combination for which the reference leaves its result unassigned
+ * (both points within 1e-7 of the photon) also gives 0. */
+static int cylinder_intersect(const rtmc_element *e, const double *L, const double *D, int was_element, double *B)
+{
+    double p1[3], p2[3];
+    int ok1, ok2;
+    cylinder_line(e, L, D, p1, &ok1, p2, &ok2);
+    if (!was_element) { /* :102-107 */
+        int k = D[0] != 0 ? 0 : (D[1] != 0 ? 1 : 2);
+        if (ok1 && (p1[k] - L[k]) / D[k] < 0) ok1 = 0;
+        if (ok2 && (p2[k] - L[k]) / D[k] < 0) ok2 = 0;
+    }
+    const double *pick = NULL;
+    if (ok1 && ok2) {
+        double d1v[3] = {p1[0] - L[0], p1[1] - L[1], p1[2] - L[2]};
+        double d2v[3] = {p2[0] - L[0], p2[1] - L[1], p2[2] - L[2]};
+        double d1 = norm3(d1v), d2 = norm3(d2v);
+        if (d1 > 1e-7 && d2 > 1e-7) pick = d1 < d2 ? p1 : p2;
+        if (d1 > 1e-7 && d2 <= 1e-7) pick = p1;
+        if (d1 <= 1e-7 && d2 > 1e-7) pick = p2;
+    } else if (ok1)
+        pick = p1;
+    else if (ok2)
+        pick = p2;
+    if (!pick) return 0;
+    memcpy(B, pick, 3 * sizeof(double));
+    return 1;
+}
+
+/* Geometries.py:138-153,207-209 Cylinder.OperationPlane at point P */
+static void cylinder_plane(const rtmc_element *e, const double *P, double *S, double *n)
+{
+    double d[3] = {e->normal[0] - e->support[0], e->normal[1] - e->support[1], e->normal[2] - e->support[2]};
+    double nd = norm3(d);
+    d[0] /= nd; d[1] /= nd; d[2] /= nd;
+    double pa[3] = {P[0] - e->support[0], P[1] - e->support[1], P[2] - e->support[2]};
+    double k = dot3(pa, d);
+    for (int j = 0; j < 3; j++) n[j] = (e->support[j] + k * d[j]) - P[j];
+    double nn = norm3(n);
+    for (int j = 0; j < 3; j++) { n[j] /= nn; S[j] = P[j]; }
+}
+
+/* Geometry.OperationPlane() of element `el` for a photon whose candidate point is P */
+static void operation_plane(const orc_scene *s, int el, const double *P, double *S, double *n)
+{
+    const rtmc_element *e = &s->el[el];
+    if (e->geometry == RTMC_GEOM_CYLINDER) { cylinder_plane(e, P, S, n); return; }
+    memcpy(S, e->support, 3 * sizeof(double));
+    memcpy(n, e->normal, 3 * sizeof(double));
+}
+
+static int element_intersect(const rtmc_element *e, const double *L, const double *D, int was_element, double *B)
+{
+    switch (e->geometry) {
+    case RTMC_GEOM_RECTANGLE: return rect_intersect(e, L, D, B);
+    case RTMC_GEOM_CIRCLE: return circle_intersect(e, L, D, B);
+    case RTMC_GEOM_TRIANGLE: return triangle_intersect(e, L, D, B);
+    case RTMC_GEOM_CYLINDER: return cylinder_intersect(e, L, D, was_element, B);
+    }
+    return 0;
+}
+
 /* RTUtils.py:6-11 CheckSides */
 static int check_sides(const double *v1, const double *v2, const double *S, const double *n)
 {
@@ -586,7 +733,7 @@ static void find_crossing(const orc_scene *s, ph_t *p)
     p->point_cy[0] = p->point_cy[1] = p->point_cy[2] = 0;
     for (int i = 0; i < s->n_el; i++) {
         double pt[3];
-        if (!rect_intersect(&s->el[i], p->L, p->D, pt)) continue;
+        if (!element_intersect(&s->el[i], p->L, p->D, p->was_element, pt)) continue;
         double df[3] = {p->L[0] - pt[0], p->L[1] - pt[1], p->L[2] - pt[2]};
         double dist = norm3(df);
         if (dist < p->smallest && dist > 1e-8) {
@@ -920,6 +1067,37 @@ static void mirror_op(ph_t *p, int el, rtmc_tallies *t)
     post_process(p);
 }
 
+/* PhotonObject.py:158-191 FocusThinLens */
+static void focus_thin_lens(ph_t *p, double f)
+{
+    double sl[3] = {p->op_S[0] - p->L[0], p->op_S[1] - p->L[1], p->op_S[2] - p->L[2]};
+    double t = dot3(sl, p->op_n) / dot3(p->D, p->op_n);
+    double base[3], fp1[3], fp2[3];
+    for (int j = 0; j < 3; j++) {
+        base[j] = t * p->D[j] + p->L[j];
+        fp1[j] = p->op_S[j] + f * p->op_n[j];
+        fp2[j] = p->op_S[j] - f * p->op_n[j];
+    }
+    /* the focal plane on the far side of the lens */
+    const double *fp = check_sides(p->L, fp1, p->op_S, p->op_n) ? fp2 : fp1;
+    /* "thin cylindrical lens": the parallel ray starts at the hit point's x, y and the lens centre's z */
+    double pr[3] = {base[0], base[1], p->op_S[2]};
+    double d2[3] = {fp[0] - pr[0], fp[1] - pr[1], fp[2] - pr[2]};
+    double t2 = dot3(d2, p->op_n) / dot3(p->D, p->op_n);
+    double dv[3];
+    for (int j = 0; j < 3; j++) dv[j] = -((t2 * p->D[j] + pr[j]) - base[j]);
+    double n = norm3(dv);
+    for (int j = 0; j < 3; j++) { p->L[j] = base[j]; p->D[j] = dv[j] / n; }
+}
+
+/* Elements.py:125-129 Lens.ExecuteOperation */
+static void lens_op(const orc_scene *s, ph_t *p, int el)
+{
+    prepare_execution(p);
+    focus_thin_lens(p, s->el[el].focal_length);
+    post_process(p);
+}
+
 /* Elements.py:152-169 Dump.ExecuteOperation */
 static void dump_op(const orc_scene *s, ph_t *p, rng_t *g, int el, rtmc_tallies *t)
 {
@@ -972,9 +1150,9 @@ static int loop_iteration(const orc_scene *s, ph_t *p, rng_t *g, rtmc_tallies *t
     memcpy(p->drv_old_point, p->old_point, sizeof p->old_point);
     if (p->status == RTMC_ST_START) {
         const rtmc_element *e = &s->el[p->old_el];
-        memcpy(p->op_S, e->support, sizeof p->op_S);
-        memcpy(p->op_n, e->normal, sizeof p->op_n);
+        operation_plane(s, p->old_el, p->point_cy, p->op_S, p->op_n); /* RayTrace.py:187 */
         if (e->type == RTMC_TYPE_INTERFACE) interface_op(s, p, g, p->old_el, t);
+        else if (e->type == RTMC_TYPE_LENS) lens_op(s, p, p->old_el);
         else if (e->type == RTMC_TYPE_MIRROR) mirror_op(p, p->old_el, t);
         else if (e->type == RTMC_TYPE_DUMP) dump_op(s, p, g, p->old_el, t);
         memcpy(p->drv_old_point, p->old_point, sizeof p->old_point);
@@ -1038,10 +1216,8 @@ static void soa_load(const rtmc_photon_soa *b, uint32_t k, ph_t *p, const orc_sc
     p->was_element = b->was_element[k]; p->reflected = b->reflected[k];
     p->iter = b->iterations[k];
     p->smallest = INFINITY;
-    if (p->old_el >= 0 && p->old_el < s->n_el) {
-        memcpy(p->op_S, s->el[p->old_el].support, sizeof p->op_S);
-        memcpy(p->op_n, s->el[p->old_el].normal, sizeof p->op_n);
-    }
+    /* the operation plane of the last element; a photon that left a cylinder sits on its tangent plane */
+    if (p->old_el >= 0 && p->old_el < s->n_el) operation_plane(s, p->old_el, p->L, p->op_S, p->op_n);
 }
 static void soa_store(rtmc_photon_soa *b, uint32_t k, const ph_t *p, const rng_t *g, uint64_t tape_base)
 {
@@ -1098,7 +1274,7 @@ ORC_EXPORT int orc_op_intersect(const orc_scene *s, uint32_t n, const double *lo
     for (uint32_t k = 0; k < n; k++)
         for (int i = 0; i < s->n_el; i++) {
             double *o = out + ((uint64_t)k * s->n_el + i) * 3;
-            if (!rect_intersect(&s->el[i], loc + 3 * k, dir + 3 * k, o)) o[0] = o[1] = o[2] = NAN;
+            if (!element_intersect(&s->el[i], loc + 3 * k, dir + 3 * k, 0, o)) o[0] = o[1] = o[2] = NAN;
         }
     return RTMC_OK;
 }

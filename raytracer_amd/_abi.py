@@ -40,7 +40,7 @@ class Element(C.Structure):
                 ("half1", C.c_double), ("half2", C.c_double),
                 ("material1", C.c_int32), ("material2", C.c_int32),
                 ("eqe_table", C.c_int32), ("reserved", C.c_int32),
-                ("focal_length", C.c_double)]
+                ("focal_length", C.c_double), ("vertex3", c_double3)]
 
 
 class Table(C.Structure):

@@ -131,6 +131,44 @@ def stacked_job(n_photons=10000):
     }
 
 
+def rod_job(n_photons=10000):
+    """All element shapes and types in one scene: a dye-filled rod (cylinder
+    wall + two circular caps, interfaces air/LR) lying along y, a thin lens
+    (circle) between the source and the rod, a triangular mirror below, a small
+    detector tube beside the rod, and a closed detector box around everything.
+    Hemispherical 460 nm source beside the lens.  The lens faces x: the
+    reference's thin lens focuses along z only (PhotonObject.py:178) and does
+    nothing but reverse the direction vector when its normal is the z axis."""
+    from .RTUtils import MakeTriangle
+    els, props, geom, sizes = [], [], [], []
+
+    def add(element, prop, g, size):
+        els.append(element); props.append(prop); geom.append(g); sizes.append(size)
+
+    p1, p2, r = [0.0, -1.5, 0.0], [0.0, 1.5, 0.0], 0.5
+    add([p1, p2], [2, "air", "LR"], 3, [r])                           # rod wall: axis end points
+    add([p1, [0.0, 1.0, 0.0]], [2, "air", "LR"], 2, [r])              # caps
+    add([p2, [0.0, 1.0, 0.0]], [2, "LR", "air"], 2, [r])
+    add([[1.3, 0.0, 0.0], [1.0, 0.0, 0.0]], [3, 0.8], 2, [0.6])       # lens
+    tri = [[-1.5, -1.5, -1.0], [1.5, -1.5, -1.2], [0.0, 1.5, -0.8]]
+    s, n = MakeTriangle(*tri)
+    add([list(s), list(n)], [1], 4, tri)                              # mirror
+    add([[-1.5, -1.0, -0.5], [-2.0, 1.0, 0.5]], [4, 0, 0, ""], 3, [0.3])  # detector tube
+    e, p, sz = _dump_box(0.0, 0.0, 0.0, 3.0, 3.0)
+    for a, b, c in zip(e, p, sz):
+        add(a, b, 1, c)
+    mats = [copy.deepcopy(AIR_ROW), dye_row("LR")]
+    photon = _photon(n_photons, (2.2, 0.1, 0.2), ISOTROPIC, FIXED_WL, 460, "air", (-1.0, 0.05, -0.1))
+    return {
+        "Elements": np.array(els, dtype=np.float64),
+        "ElementProperties": props,
+        "ElementGeometry": geom,
+        "ElementSize": sizes,
+        "Materials": mats,
+        "Photon": photon,
+    }
+
+
 def synthetic_am15():
     """Two-column stand-in for the sun table the reference expects in
     `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with
@@ -159,6 +197,8 @@ CONFIGS = {
     # donor present, emission polarisation not tied to the dipole
     "C7": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, aligned=True, align_s=0.3,
                           abs_em_angle=10, respect_pol=False)),
+    # every shape (cylinder, circle, triangle, rectangle) and type (interface, lens, mirror, detector)
+    "C8": (rod_job, dict()),
 }
 
 

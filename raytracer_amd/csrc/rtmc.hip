@@ -91,11 +91,12 @@ enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
 #ifndef RTMC_TRACE_WAVES
 #define RTMC_TRACE_WAVES 1
 #endif
-template <typename real, bool ALIGNED>
+template <typename real, int FEATURES>
 __global__ void __launch_bounds__(TRACE_BLOCK, RTMC_TRACE_WAVES)
 trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
              unsigned long long *work)
 {
+    constexpr bool ALIGNED = (FEATURES & FEAT_ALIGNED) != 0;
     extern __shared__ __align__(16) unsigned char smem[];
     SceneArg<real> sc = scene_ref(scene);
     Lds<real> lds = stage_lds(sc, smem, true);
@@ -190,7 +191,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             continue;
         }
         if (need == NEED_NONE) {
-            const StepResult r = photon_step<ALIGNED>(hot, lds, p, g, tally);
+            const StepResult r = photon_step<FEATURES>(hot, lds, p, g, tally);
             if (r == STEP_ENDED) {
                 count_fate(p, tally);
                 need = NEED_LAUNCH;
@@ -265,16 +266,22 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
         set_admissibility_forward(p);
         if ((p.flags & F_WAS_EL) && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
             const DevElem<real> &le = lds.elems[p.last_el];
-            double s = (double)le.nx * b.old_point[0][k] + (double)le.ny * b.old_point[1][k] +
-                       (double)le.nz * b.old_point[2][k] - (double)le.d0;
-            set_admissibility(p, le.type, (s > 0) - (s < 0), le.nx * p.Dx + le.ny * p.Dy + le.nz * p.Dz);
+            real nx = le.nx, ny = le.ny, nz = le.nz;
+            double d0 = (double)le.d0;
+            if ((le.type >> 8) == RTMC_GEOM_CYLINDER) {  // the photon sits on the tangent plane of its last operation
+                cylinder_normal(le, p.Lx, p.Ly, p.Lz, nx, ny, nz);
+                d0 = (double)nx * b.loc[0][k] + (double)ny * b.loc[1][k] + (double)nz * b.loc[2][k];
+            }
+            double s = (double)nx * b.old_point[0][k] + (double)ny * b.old_point[1][k] +
+                       (double)nz * b.old_point[2][k] - d0;
+            set_admissibility(p, le.type & 0xFF, (s > 0) - (s < 0), nx * p.Dx + ny * p.Dy + nz * p.Dz);
         }
     }
     NoTally tally;
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
                    p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
     for (uint32_t it = 0; it < n_steps && alive; it++) {
-        StepResult r = photon_step<true>(hot, lds, p, g, tally);
+        StepResult r = photon_step<FEAT_ALIGNED | FEAT_SHAPES>(hot, lds, p, g, tally);
         if (r == STEP_ABSORBED) {
             emit_in_reference_order(hot, lds, p, g);
             r = finish_absorbed_iteration(hot, p);
@@ -312,7 +319,8 @@ __global__ void intersect_kernel(const DevScene<real> *scene, uint32_t n, const 
     real Lx = real(loc[3 * k]), Ly = real(loc[3 * k + 1]), Lz = real(loc[3 * k + 2]);
     real Dx = real(dir[3 * k]), Dy = real(dir[3 * k + 1]), Dz = real(dir[3 * k + 2]);
     real t;
-    bool ok = rect_hit(load_uniform(sc.elems + e), Lx, Ly, Lz, Dx, Dy, Dz, t);
+    const real dnorm = M<real>::sqrt(Dx * Dx + Dy * Dy + Dz * Dz);
+    bool ok = shape_hit(load_uniform(sc.elems + e), Lx, Ly, Lz, Dx, Dy, Dz, false, false, dnorm, t);
     const double nan = __builtin_nan("");
     out[3 * idx] = ok ? (double)(Lx + t * Dx) : nan;
     out[3 * idx + 1] = ok ? (double)(Ly + t * Dy) : nan;
@@ -384,6 +392,22 @@ std::vector<double> sampling_cdf(const HostTable &t, bool times_lambda)
     return w;
 }
 
+// in-plane unit axes n1 = unit(v x x^), n2 = unit(v x n1) of MakeVectAxis (RTUtils.py:25-42; y^ if v is x^)
+void axis_frame(const double *v, double *n1, double *n2)
+{
+    const bool is_x = v[0] == 1 && v[1] == 0 && v[2] == 0;
+    const double o[3] = {is_x ? 0.0 : 1.0, is_x ? 1.0 : 0.0, 0.0};
+    auto cross = [](const double *a, const double *b, double *c) {
+        c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    auto unit = [](double *a) {
+        const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        a[0] /= n; a[1] /= n; a[2] /= n;
+    };
+    cross(v, o, n1); unit(n1);
+    cross(v, n1, n2); unit(n2);
+}
+
 // u < q  for u = v / 2^32 with integer v   <=>   v < ceil(q * 2^32);
 // the same integer serves "cdf entry <= u"  <=>  ceil(cdf * 2^32) <= v.
 uint32_t threshold32(double q)
@@ -425,6 +449,8 @@ struct PerDevice {
 struct rtmc_scene {
     int n_el = 0, n_mat = 0, n_eqe = 0, max_iter = 0;
     bool has_aligned = false;       // some medium has aligned acceptor dyes: the kernels with that code are used
+    bool has_shapes = false;        // some element is not a rectangle, or is a lens
+    int features() const { return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0); }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
@@ -466,7 +492,31 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.bx = (real)e.e2[0]; o.by = (real)e.e2[1]; o.bz = (real)e.e2[2];
         o.c2 = (real)dot(e.e2, e.support);
         o.h1 = (real)e.half1; o.h2 = (real)e.half2;
-        o.type = e.type;
+        o.sz = (real)e.support[2];
+        o.focal = (real)e.focal_length;
+        if (e.geometry == RTMC_GEOM_CIRCLE) {  // Geometries.py:75
+            o.ax = (real)e.support[0]; o.ay = (real)e.support[1]; o.az = (real)e.support[2];
+            o.h1 = (real)(e.half1 * e.half1);
+        } else if (e.geometry == RTMC_GEOM_TRIANGLE) {  // Geometries.py:232-247
+            double n1[3], n2[3];
+            axis_frame(e.normal, n1, n2);
+            const double *corner[3] = {e.e1, e.e2, e.vertex3};
+            real *q[3][2] = {{&o.c1, &o.c2}, {&o.h1, &o.h2}, {&o.g1, &o.g2}};
+            for (int c = 0; c < 3; c++) { *q[c][0] = (real)dot(n1, corner[c]); *q[c][1] = (real)dot(n2, corner[c]); }
+            o.ax = (real)n1[0]; o.ay = (real)n1[1]; o.az = (real)n1[2];
+            o.bx = (real)n2[0]; o.by = (real)n2[1]; o.bz = (real)n2[2];
+        } else if (e.geometry == RTMC_GEOM_CYLINDER) {  // Geometries.py:158-173: support/normal are the axis end points
+            double a[3] = {e.support[0] - e.normal[0], e.support[1] - e.normal[1], e.support[2] - e.normal[2]};
+            const double na = std::sqrt(dot(a, a));
+            for (int j = 0; j < 3; j++) a[j] /= na;
+            const double x1 = 0.0, x2 = dot(a, e.normal) - dot(a, e.support);  // axial coordinates relative to the first point
+            o.ax = (real)a[0]; o.ay = (real)a[1]; o.az = (real)a[2];
+            o.bx = (real)e.support[0]; o.by = (real)e.support[1]; o.bz = (real)e.support[2];
+            o.c1 = (real)(e.half1 * e.half1);
+            o.h1 = (real)std::min(x1, x2); o.h2 = (real)std::max(x1, x2);
+            o.nx = o.ny = o.nz = o.d0 = (real)0;
+        }
+        o.type = e.type | (e.geometry << 8);
         o.info = 0;
         if (e.type == RTMC_TYPE_INTERFACE) o.info = e.material1 | (e.material2 << 8);
         if (e.type == RTMC_TYPE_DUMP) o.info = ((e.eqe_table + 1) & 0xFF) | (el_slot[i] << 8);
@@ -497,7 +547,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         for (int i = 0; i < n_el; i++) {
             const rtmc_element &e = d->elements[i];
             const int kn = axis_of(e.normal), k1 = axis_of(e.e1), k2 = axis_of(e.e2);
-            const bool aligned = kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2;
+            const bool aligned = e.geometry == RTMC_GEOM_RECTANGLE && kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 &&
+                                 kn != k2 && k1 != k2;
             if ((aligned ? kn : 3) != group) continue;
             HitRec<real> h;
             memset(&h, 0, sizeof h);
@@ -671,12 +722,19 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     if (src.start_material < 0 || src.start_material >= d->n_materials) return fail(RTMC_EINVAL, "start material out of range");
     if (!(src.scale_factor > 0)) return fail(RTMC_EINVAL, "scale_factor must be positive");
     if (src.direction_mode != 0 && src.direction_mode != 1) return fail(RTMC_EINVAL, "unknown direction mode");
+    bool has_shapes = false;
     for (int i = 0; i < d->n_elements; i++) {
         const rtmc_element &e = d->elements[i];
-        if (e.geometry != RTMC_GEOM_RECTANGLE)
-            return fail(RTMC_EUNSUPPORTED, "element %d: only rectangles are built so far (geometry code %d)", i, e.geometry);
-        if (e.type != RTMC_TYPE_MIRROR && e.type != RTMC_TYPE_INTERFACE && e.type != RTMC_TYPE_DUMP)
-            return fail(RTMC_EUNSUPPORTED, "element %d: element type code %d is not built so far", i, e.type);
+        if (e.geometry < RTMC_GEOM_RECTANGLE || e.geometry > RTMC_GEOM_TRIANGLE)
+            return fail(RTMC_EINVAL, "element %d: unknown geometry code %d", i, e.geometry);
+        if (e.type < RTMC_TYPE_MIRROR || e.type > RTMC_TYPE_DUMP)
+            return fail(RTMC_EINVAL, "element %d: unknown element type code %d", i, e.type);
+        if (e.geometry != RTMC_GEOM_RECTANGLE || e.type == RTMC_TYPE_LENS) has_shapes = true;
+        if (e.geometry == RTMC_GEOM_CYLINDER) {
+            double len2 = 0;
+            for (int j = 0; j < 3; j++) len2 += (e.support[j] - e.normal[j]) * (e.support[j] - e.normal[j]);
+            if (!(len2 > 0) || !(e.half1 > 0)) return fail(RTMC_EINVAL, "element %d: cylinder needs two distinct axis points and a radius", i);
+        }
         if (e.type == RTMC_TYPE_INTERFACE &&
             (e.material1 < 0 || e.material1 >= d->n_materials || e.material2 < 0 || e.material2 >= d->n_materials))
             return fail(RTMC_EINVAL, "element %d: interface material out of range", i);
@@ -746,6 +804,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     rtmc_scene *s = new rtmc_scene;
     s->n_el = d->n_elements; s->n_mat = d->n_materials; s->n_eqe = d->n_tables; s->max_iter = d->max_iterations;
     s->has_aligned = has_aligned;
+    s->has_shapes = has_shapes;
     s->elements.assign(d->elements, d->elements + d->n_elements);
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
@@ -827,6 +886,18 @@ RTMC_API int rtmc_scene_wavelengths(const rtmc_scene *s, int64_t *count, double 
 
 static int upload_scene_structs(rtmc_scene *s, PerDevice &p);
 
+// the trace kernel instantiation for a feature set
+template <typename real>
+static const void *trace_function(int features)
+{
+    switch (features) {
+    case 0: return (const void *)trace_kernel<real, 0>;
+    case 1: return (const void *)trace_kernel<real, 1>;
+    case 2: return (const void *)trace_kernel<real, 2>;
+    default: return (const void *)trace_kernel<real, 3>;
+    }
+}
+
 // upload the scene to `device` on first use; leaves that device current
 static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
 {
@@ -875,8 +946,8 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     p.n_cu = prop.multiProcessorCount;
-    const void *trace32 = s->has_aligned ? (const void *)trace_kernel<float, true> : (const void *)trace_kernel<float, false>;
-    const void *trace64 = s->has_aligned ? (const void *)trace_kernel<double, true> : (const void *)trace_kernel<double, false>;
+    const void *trace32 = trace_function<float>(s->features());
+    const void *trace64 = trace_function<double>(s->features());
     HIP_TRY(hipFuncSetAttribute(trace32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
     HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks32, trace32, TRACE_BLOCK, s->img32.lay.total));
@@ -959,18 +1030,13 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
     HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
-    if (f32 && !s->has_aligned)
-        hipLaunchKernelGGL((trace_kernel<float, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           (const DevScene<float> *)p.scene32, tl, seed, first_photon, n_photons, p.work);
-    else if (f32)
-        hipLaunchKernelGGL((trace_kernel<float, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           (const DevScene<float> *)p.scene32, tl, seed, first_photon, n_photons, p.work);
-    else if (!s->has_aligned)
-        hipLaunchKernelGGL((trace_kernel<double, false>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           (const DevScene<double> *)p.scene64, tl, seed, first_photon, n_photons, p.work);
-    else
-        hipLaunchKernelGGL((trace_kernel<double, true>), dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
-                           (const DevScene<double> *)p.scene64, tl, seed, first_photon, n_photons, p.work);
+    {
+        const void *scene_ptr = f32 ? p.scene32 : p.scene64;
+        unsigned long long *work = p.work;
+        void *args[] = {&scene_ptr, &tl, &seed, &first_photon, &n_photons, &work};
+        const void *fn = f32 ? trace_function<float>(s->features()) : trace_function<double>(s->features());
+        HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(TRACE_BLOCK), args, lds_bytes, p.stream));
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p.ev1, p.stream));
     std::vector<unsigned long long> host(p.tally_words);

@@ -32,20 +32,27 @@ namespace rtmc {
 // ---------------------------------------------------------------------------
 
 // One element as the optical operation sees it (first three 16-byte groups,
-// gathered per lane from LDS) and as the general hit test sees it.
-// plane: n.x = d0; in-plane coordinates t1 = a.x - c1, t2 = b.x - c2.
+// gathered per lane from LDS) and as the general hit test sees it (last three
+// groups, meaning by shape):
+//   rectangle  plane n.x = d0; in-plane coordinates t1 = a.x - c1, t2 = b.x - c2, half extents h1, h2
+//   circle     a = centre, h1 = radius^2
+//   triangle   a, b = in-plane unit axes; corners in that frame (c1,c2) (h1,h2) (g1,g2)
+//   cylinder   a = unit axis, b = an axis point, c1 = radius^2, wall between axial
+//              coordinates h1 <= a.(x - b) <= h2; the plane of an operation is the
+//              tangent plane at the point hit, so n and d0 are not used
 template <typename real>
 struct DevElem {
     real nx, ny, nz, d0;
-    int32_t type;   // RTMC_TYPE_*
+    int32_t type;   // RTMC_TYPE_* | RTMC_GEOM_* << 8
     int32_t info;   // interface: material1 | material2 << 8; dump: (eqe table + 1) | detector slot << 8
     int32_t nid1;   // interface: name id of material1 (Elements.py:45 compares names)
     int32_t slots;  // interface: (absorption slot of material1 + 1) | (slot of material2 + 1) << 16
     real n1v, n2v;  // interface: refractive indices of material1 / material2
-    real pad0, pad1;
+    real focal;     // lens: focal length
+    real sz;        // z coordinate of the support point (PhotonObject.py:178)
     real ax, ay, az, c1;
     real bx, by, bz, c2;
-    real h1, h2, pad2, pad3;
+    real h1, h2, g1, g2;
 };
 
 // An element as the nearest-hit search sees it.  The table is grouped by the
@@ -774,6 +781,110 @@ __device__ __forceinline__ bool axis_hit(const HitRec<real> &r, real inv_dk, rea
     return (M<real>::abs(Bi - r.ci) <= r.hi) & (M<real>::abs(Bj - r.cj) <= r.hj);
 }
 
+// Geometries.py:68-80 Circle.FindIntersections
+template <typename real>
+__device__ __forceinline__ bool circle_hit(const DevElem<real> &e, real Lx, real Ly, real Lz, real Dx, real Dy,
+                                           real Dz, real &t)
+{
+    real den = Dx * e.nx + Dy * e.ny + Dz * e.nz;
+    t = (e.d0 - (Lx * e.nx + Ly * e.ny + Lz * e.nz)) * M<real>::rcp(den);
+    real x = Lx + t * Dx - e.ax, y = Ly + t * Dy - e.ay, z = Lz + t * Dz - e.az;
+    return (den != real(0)) & (x * x + y * y + z * z <= e.h1);
+}
+
+// Geometries.py:220-251 Triangle.FindIntersections / CheckPointInTriangle: the
+// point and the corners in the in-plane frame, three edge functions of equal sign
+template <typename real>
+__device__ __forceinline__ bool triangle_hit(const DevElem<real> &e, real Lx, real Ly, real Lz, real Dx, real Dy,
+                                             real Dz, real &t)
+{
+    real den = Dx * e.nx + Dy * e.ny + Dz * e.nz;
+    t = (e.d0 - (Lx * e.nx + Ly * e.ny + Lz * e.nz)) * M<real>::rcp(den);
+    real Bx = Lx + t * Dx, By = Ly + t * Dy, Bz = Lz + t * Dz;
+    real u = Bx * e.ax + By * e.ay + Bz * e.az, v = Bx * e.bx + By * e.by + Bz * e.bz;
+    // SclPrdSign(pt, q_i, q_j) = (pt.x - qj.x)(qi.y - qj.y) - (qi.x - qj.x)(pt.y - qj.y)
+    bool b1 = (u - e.h1) * (e.c2 - e.h2) - (e.c1 - e.h1) * (v - e.h2) < real(0);
+    bool b2 = (u - e.g1) * (e.h2 - e.g2) - (e.h1 - e.g1) * (v - e.g2) < real(0);
+    bool b3 = (u - e.c1) * (e.g2 - e.c2) - (e.g1 - e.c1) * (v - e.c2) < real(0);
+    return (den != real(0)) & (b1 == b2) & (b2 == b3);
+}
+
+// Geometries.py:97-136,156-204 Cylinder.FindIntersections: of the two points
+// where the line meets the wall, the one the reference hands to the search.
+//   fresh photon (not coming from an element): points behind it are dropped;
+//   both left: the nearer one, unless one of them is the photon's own position
+//   (within 1e-7), then the other; one left: that one.
+// `sitting`: the photon's last operation was on this cylinder.  In float32 the
+// 1e-7 test cannot tell the photon's own position; there the root of smaller
+// magnitude is taken to be it when the photon sits on the wall.
+template <typename real>
+__device__ __forceinline__ bool cylinder_hit(const DevElem<real> &e, real Lx, real Ly, real Lz, real Dx, real Dy,
+                                             real Dz, bool was_element, bool sitting, real dnorm, real &t)
+{
+    const real wx = Lx - e.bx, wy = Ly - e.by, wz = Lz - e.bz;
+    const real da = Dx * e.ax + Dy * e.ay + Dz * e.az, wa = wx * e.ax + wy * e.ay + wz * e.az;
+    const real px = Dx - da * e.ax, py = Dy - da * e.ay, pz = Dz - da * e.az;  // across the axis
+    const real qx = wx - wa * e.ax, qy = wy - wa * e.ay, qz = wz - wa * e.az;
+    const real a1 = px * px + py * py + pz * pz;
+    const real a2 = real(2) * (px * qx + py * qy + pz * qz);
+    const real a3 = qx * qx + qy * qy + qz * qz - e.c1;
+    const real dsc = a2 * a2 - real(4) * a1 * a3;
+    const bool any = (a1 != real(0)) & ((dsc >= real(0)) | (!M<real>::has_self_hit_eps & sitting));
+    const real sq = M<real>::sqrt(dsc > real(0) ? dsc : real(0));
+    const real inv = M<real>::rcp(real(2) * a1);
+    real t1 = (-a2 + sq) * inv, t2 = (-a2 - sq) * inv;
+    if (!M<real>::has_self_hit_eps && sitting) {
+        // on the wall a3 is zero up to rounding: one root is the photon's own
+        // position and the other is -a2/a1 exactly, which is far better
+        // conditioned in float32 for a grazing ray than the root formula
+        const real other = -a2 * M<real>::rcp(a1);
+        t1 = a2 < real(0) ? other : real(0);
+        t2 = a2 < real(0) ? real(0) : other;
+    }
+    const real x1 = wa + t1 * da, x2 = wa + t2 * da;  // axial coordinates
+    bool ok1 = any & !(x1 < e.h1) & !(x1 > e.h2);
+    bool ok2 = any & !(x2 < e.h1) & !(x2 > e.h2);
+    if (!was_element) { ok1 = ok1 & !(t1 < real(0)); ok2 = ok2 & !(t2 < real(0)); }
+    const real d1 = M<real>::abs(t1) * dnorm, d2 = M<real>::abs(t2) * dnorm;
+    bool own1, own2;
+    if (M<real>::has_self_hit_eps) {
+        own1 = d1 <= real(1e-7); own2 = d2 <= real(1e-7);
+    } else {
+        own1 = sitting & (d1 <= d2); own2 = sitting & (d2 < d1);
+    }
+    const bool both = ok1 & ok2;
+    const bool take1 = both ? (!own1 & (own2 | (d1 < d2))) : ok1;
+    const bool take2 = both ? (!own2 & (own1 | !(d1 < d2))) : (ok2 & !ok1);
+    t = take1 ? t1 : t2;
+    bool hit = take1 | take2;
+    if (!M<real>::has_self_hit_eps) hit = hit & !(take1 ? own1 : own2);  // RayTrace.py:134 rejects the own position
+    return hit;
+}
+
+// Geometries.py:138-153,207-209: unit normal of a cylinder's tangent plane at
+// P, pointing from P to the axis.
+template <typename real>
+__device__ __forceinline__ void cylinder_normal(const DevElem<real> &e, real Px, real Py, real Pz, real &nx, real &ny,
+                                                real &nz)
+{
+    const real wx = Px - e.bx, wy = Py - e.by, wz = Pz - e.bz;
+    const real wa = wx * e.ax + wy * e.ay + wz * e.az;
+    nx = wa * e.ax - wx; ny = wa * e.ay - wy; nz = wa * e.az - wz;
+    normalize3(nx, ny, nz);
+}
+
+// FindIntersections of an element of any shape.
+template <typename real>
+__device__ __forceinline__ bool shape_hit(const DevElem<real> &e, real Lx, real Ly, real Lz, real Dx, real Dy,
+                                          real Dz, bool was_element, bool sitting, real dnorm, real &t)
+{
+    const int geom = e.type >> 8;
+    if (geom == RTMC_GEOM_CIRCLE) return circle_hit(e, Lx, Ly, Lz, Dx, Dy, Dz, t);
+    if (geom == RTMC_GEOM_TRIANGLE) return triangle_hit(e, Lx, Ly, Lz, Dx, Dy, Dz, t);
+    if (geom == RTMC_GEOM_CYLINDER) return cylinder_hit(e, Lx, Ly, Lz, Dx, Dy, Dz, was_element, sitting, dnorm, t);
+    return rect_hit(e, Lx, Ly, Lz, Dx, Dy, Dz, t);
+}
+
 // Running minimum of the nearest-hit search.
 template <typename real>
 struct Nearest {
@@ -853,14 +964,20 @@ struct NoTally {
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 
+// Code a scene may need beyond rectangles with isotropic dyes; kernels are
+// instantiated per combination so that the common case carries none of it.
+enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2 };
+
 // One iteration of the loop body, RayTrace.py:178-195, up to the point where an
 // absorbed photon needs its pathway drawn: the caller does that
 // (emit_in_reference_order / the renew block of the trace kernel) and then
 // calls finish_absorbed_iteration.
-template <bool ALIGNED, typename real, bool TAPE, typename Tally>
+template <int FEATURES, typename real, bool TAPE, typename Tally>
 __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, const Lds<real> &lds,
                                                   Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
 {
+    constexpr bool ALIGNED = (FEATURES & FEAT_ALIGNED) != 0;
+    constexpr bool SHAPES = (FEATURES & FEAT_SHAPES) != 0;
     // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
     // Candidates are ordered by |t| (the line parameter); the distance is
     // |t| |D|.  Admissibility: see set_admissibility.  The element the photon
@@ -889,8 +1006,16 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
                 const int index = ch.r[k].index;
                 if (index < 0) continue;  // padding
                 real t;
-                const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
-                consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
+                if (SHAPES) {
+                    const DevElem<real> e = load_uniform(sc.elems + index);
+                    const bool wall = (e.type >> 8) == RTMC_GEOM_CYLINDER;  // may be met again right away
+                    const bool inside = shape_hit(e, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, (p.flags & F_WAS_EL) != 0u,
+                                                  index == skip, dnorm, t);
+                    consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm);
+                } else {
+                    const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
+                    consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
+                }
             }
         }
     }
@@ -941,11 +1066,20 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     // ---- the element's ExecuteOperation -------------------------------------
     {
         const DevElem<real> &el = lds.elems[el_idx];  // per-lane gather from LDS
-        const real nx = el.nx, ny = el.ny, nz = el.nz;
-        const int type = el.type, info = el.info;
+        real nx = el.nx, ny = el.ny, nz = el.nz, d0 = el.d0;
+        const int type = el.type & 0xFF, info = el.info;
+        if (SHAPES) {
+            if ((el.type >> 8) == RTMC_GEOM_CYLINDER) {
+                // RayTrace.py:187: tangent plane at the candidate point (the origin if nothing was found)
+                const real Px = stale ? real(0) : p.Lx + best_t * p.Dx, Py = stale ? real(0) : p.Ly + best_t * p.Dy,
+                           Pz = stale ? real(0) : p.Lz + best_t * p.Dz;
+                cylinder_normal(el, Px, Py, Pz, nx, ny, nz);
+                d0 = nx * Px + ny * Py + nz * Pz;
+            }
+        }
         // PhotonObject.py:135-139 PrepareExecution
         const real dn = p.Dx * nx + p.Dy * ny + p.Dz * nz;
-        const real off = p.Lx * nx + p.Ly * ny + p.Lz * nz - el.d0;  // signed distance of the segment start
+        const real off = p.Lx * nx + p.Ly * ny + p.Lz * nz - d0;  // signed distance of the segment start
         const real sgn = real(sgn_i(-dn));
         const real oDx = p.Dx, oDy = p.Dy, oDz = p.Dz;
         p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
@@ -973,6 +1107,27 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             return STEP_ENDED;
         }
         bool reflect = true;
+        bool have_axis = false;  // D_new x D_old already known
+        real cx = real(0), cy = real(0), cz = real(0);
+        if (SHAPES) {
+            if (type == RTMC_TYPE_LENS) {  // Elements.py:125-129, PhotonObject.py:158-191
+                reflect = false;
+                // the focal plane on the far side: S + fo n, fo = -f if the photon came from the side of S + f n
+                const real f = el.focal;
+                const real fo = (sgn_i(off) == sgn_i(f)) ? -f : f;
+                // parallel ray through (x, y of the hit point, z of the lens centre), PhotonObject.py:178
+                const real gz = el.sz - p.Lz;
+                const real t2 = (fo - nz * gz) * M<real>::rcp(dn);  // (FP - PR0).n / (D.n); the hit point is on the plane
+                real vx = -(t2 * p.Dx), vy = -(t2 * p.Dy), vz = -(gz + t2 * p.Dz);
+                const real iv = M<real>::rsqrt(vx * vx + vy * vy + vz * vz);
+                // D_new x D_old = -((0,0,gz) x D_old) / |v|: the part of v along D_old drops out
+                // (the two directions are nearly antiparallel, their cross product taken
+                // numerically would lose most of its digits in float32)
+                have_axis = true;
+                cx = gz * p.Dy * iv; cy = -gz * p.Dx * iv; cz = real(0);
+                p.Dx = vx * iv; p.Dy = vy * iv; p.Dz = vz * iv;
+            }
+        }
         if (type == RTMC_TYPE_INTERFACE) {  // Elements.py:41-73
             // the medium on the far side, chosen by name (Elements.py:45-48)
             const bool from1 = m.name_id == el.nid1;
@@ -1031,7 +1186,9 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
         // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old)
 #ifndef RTMC_ABLATE_ROTATE
         {
-            real cx = p.Dy * oDz - p.Dz * oDy, cy = p.Dz * oDx - p.Dx * oDz, cz = p.Dx * oDy - p.Dy * oDx;
+            if (!have_axis) {
+                cx = p.Dy * oDz - p.Dz * oDy; cy = p.Dz * oDx - p.Dx * oDz; cz = p.Dx * oDy - p.Dy * oDx;
+            }
             real c2n = cx * cx + cy * cy + cz * cz;
             if (c2n != real(0)) {
                 real nn = p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz;

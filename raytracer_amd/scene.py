@@ -138,8 +138,9 @@ def pack_element(oe, mats, pool, eqe_tables):
     elif g.kind == "Triangle":
         e.support = _abi.c_double3(*g.SupportVector)
         e.normal = _abi.c_double3(*g.DirectionVector)
-        e.e1 = _abi.c_double3(*(g.TrianglePoint2 - g.TrianglePoint1))
-        e.e2 = _abi.c_double3(*(g.TrianglePoint3 - g.TrianglePoint1))
+        e.e1 = _abi.c_double3(*g.TrianglePoint1)
+        e.e2 = _abi.c_double3(*g.TrianglePoint2)
+        e.vertex3 = _abi.c_double3(*g.TrianglePoint3)
     elif g.kind == "Cylinder":
         e.support = _abi.c_double3(*g.SupportVector)
         e.normal = _abi.c_double3(*g.DirectionVector)

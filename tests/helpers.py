@@ -8,7 +8,7 @@ from raytracer_amd import RayTrace, configs
 from raytracer_amd import scene as sc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TRACE_CONFIGS = ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7"]
+TRACE_CONFIGS = ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"]
 
 # columns of a golden trace row (tests/golden/make_golden.py ROW_FIELDS)
 G_L, G_D, G_E = slice(0, 3), slice(3, 6), slice(6, 9)
@@ -40,16 +40,17 @@ def replay(scene_like, g, **kw):
     return tr, batch
 
 
-def compare_trace(g, tr, rtol, absorber_mats, atol_len=0.0):
+def compare_trace(g, tr, rtol, absorber_mats, atol_len=0.0, max_rows=None):
     """Max relative deviation of (L, D, E, wavelength, dist_left) and exact
     agreement of status / material / hit element / tape position, per photon.
     dist_left is only compared inside absorbers: in other media the reference
-    carries a stale value over from the previous photon."""
+    carries a stale value over from the previous photon.  `max_rows` limits the
+    comparison to the first iterations of every photon."""
     rows, ro = g["rows"], g["row_off"]
     worst = 0.0
     mismatched = []
     for k in range(len(g["n_iter"])):
-        r = rows[ro[k]:ro[k + 1]]
+        r = rows[ro[k]:ro[k + 1]][:max_rows]
         t = tr[k, :len(r)]
         ok = (np.array_equal(r[:, G_STATUS], t[:, T_STATUS])
               and np.array_equal(r[:, G_MAT], t[:, T_MAT])

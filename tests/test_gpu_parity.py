@@ -46,7 +46,7 @@ def test_f64_tape_replay_matches_reference(scenes, name):
     assert len(bad) <= allowed, "photons off the reference path: %s (worst %.2e)" % (bad[:10], worst)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
 def test_f32_tape_replay_follows_reference(scenes, name):
     """float32 kernels on the reference's variates: same discrete path for
     (nearly) every photon and vectors within 2e-5 after a whole trajectory
@@ -55,7 +55,9 @@ def test_f32_tape_replay_follows_reference(scenes, name):
     rt, s = scenes(name)
     tr, batch = H.replay(s, g, precision=_abi.F32)
     absorbers = [i for i, m in enumerate(s.packed.materials) if m.IsAbsorber]
-    worst, bad = H.compare_trace(g, tr, 2e-4, absorbers)
+    # a photon trapped in the rod of C8 bounces off the curved wall hundreds of
+    # times and every bounce multiplies a deviation: compare its first 30 iterations
+    worst, bad = H.compare_trace(g, tr, 2e-4, absorbers, max_rows=30 if name == "C8" else None)
     assert len(bad) <= max(1, len(g["n_iter"]) // 50), (bad[:10], worst)
 
 
@@ -72,7 +74,7 @@ def _oracle_states(oracle_mod, rt, g, max_iter):
     return states
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
 def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     """One loop iteration from identical input state and identical variates:
     float32 positions, directions, polarisation and free path agree with the
@@ -104,6 +106,7 @@ def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     scale = 5.0
     bad_discrete = 0
     worst = 0.0
+    where = None
     for j, (i, k) in enumerate(picks):
         ref = states[i + 1]
         same = all(big[key][j] == ref[key][k] for key in
@@ -114,13 +117,14 @@ def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
             continue
         for key, denom in (("loc", scale), ("dir", 1.0), ("efield", 1.0)):
             err = np.abs(big[key][:, j] - ref[key][:, k]).max() / denom
-            worst = max(worst, err)
+            if err > worst:
+                worst, where = err, (key, i, k, int(states[i]["last_element"][k]), int(ref["last_element"][k]))
         in_abs = rt.Scene().packed.materials[int(ref["material"][k])].IsAbsorber
         if in_abs and ref["dist_left"][k] < 1e30:
             d = abs(big["dist_left"][j] - ref["dist_left"][k]) / max(scale, abs(ref["dist_left"][k]))
             worst = max(worst, d)
     assert bad_discrete <= max(1, len(picks) // 2000), (bad_discrete, len(picks))
-    assert worst < 1e-6, worst
+    assert worst < 1e-6, (worst, where)
 
 
 def test_rectangle_known_answers_on_gpu(golden_dir):
@@ -148,7 +152,7 @@ def _sigma(n, p):
     return max(1.0, (n * p * (1 - p)) ** 0.5)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
 def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     """Same seed, same Philox stream, float64 on both sides: every integer
     tally is identical except for the odd photon that passes within rounding
@@ -170,7 +174,7 @@ def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     assert np.abs(gpu["energy_fx"].astype(np.int64) - cpu["energy_fx"].astype(np.int64)).max() <= 8 << 24
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
 def test_f32_follows_f64_photon_for_photon(scenes, name):
     """float32 production kernels against the float64 instantiation on the
     same 5e6 photons: a photon changes fate only when it passes within
@@ -182,10 +186,12 @@ def test_f32_follows_f64_photon_for_photon(scenes, name):
     moved = int(np.abs(a["counter"].astype(np.int64) - b["counter"].astype(np.int64)).sum())
     moved += abs(int(a["n_internal_converted"]) - int(b["n_internal_converted"]))
     assert moved <= n // 50000, moved
-    assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= n // 2000
+    # C8: a photon trapped in the rod until the iteration cap in one precision
+    # and released a little earlier in the other shifts the total by up to 1e4
+    assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= (n // 2000 if name != "C8" else int(b["n_steps"]) // 1000)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C1_open"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C1_open"])
 def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     """Production path against the reference's own seeded runs
     (tests/golden/ref_tallies.json): every detector count, internal

@@ -62,9 +62,13 @@ def test_scene_create_validates_without_gpu():
     assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == -1
     assert b"ABI version" in lib.rtmc_last_error()
     packed.desc.abi_version = _abi.ABI_VERSION
-    packed.el_array[0].geometry = 3
-    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == -2
-    assert b"rectangles" in lib.rtmc_last_error()
+    packed.el_array[0].geometry = 9
+    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == -1
+    assert b"geometry" in lib.rtmc_last_error()
+    packed.el_array[0].geometry = 3           # a cylinder whose two axis points coincide
+    packed.el_array[0].normal = packed.el_array[0].support
+    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == -1
+    assert b"cylinder" in lib.rtmc_last_error()
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -1,0 +1,44 @@
+"""Print where GPU tape replays leave the golden trace (debug aid).
+usage: python tools/dbg_trace.py CONFIG [f32|f64] [max_photons]"""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import helpers as H  # noqa: E402
+from raytracer_amd import _abi  # noqa: E402
+
+np.set_printoptions(precision=7, suppress=True, linewidth=220)
+name = sys.argv[1]
+prec = _abi.F32 if len(sys.argv) > 2 and sys.argv[2] == "f32" else _abi.F64
+limit = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+g = H.load_trace(name)
+rt = H.raytrace_for(name)
+s = rt.Scene()
+tr, batch = H.replay(s, g, precision=prec)
+rows, ro = g["rows"], g["row_off"]
+kinds = ["%d:%s/%s" % (i, oe.Geometry.kind[:4], oe.Type.kind[:4]) for i, oe in enumerate(rt.OpticalElements)]
+print(kinds)
+shown = 0
+hist = {}
+for k in range(len(g["n_iter"])):
+    r = rows[ro[k]:ro[k + 1]]
+    t = tr[k, :len(r)]
+    for i in range(len(r)):
+        same = (r[i, H.G_STATUS] == t[i, H.T_STATUS] and r[i, H.G_MAT] == t[i, H.T_MAT]
+                and r[i, H.G_HIT] == t[i, H.T_HIT] and r[i, H.G_TAPE] - g["tape_off"][k] == t[i, H.T_TAPE])
+        err = np.abs(r[i, :9] - t[i, :9]).max()
+        if not same or not err < 1e-6:
+            key = (int(r[i - 1, H.G_HIT]) if i else -1, int(r[i, H.G_HIT]), int(t[i, H.T_HIT]))
+            hist[key] = hist.get(key, 0) + 1
+            if shown < limit:
+                shown += 1
+                print("photon", k, "iteration", i, "of", len(r), "(prev hit, ref hit, got hit) =", key)
+                for j in range(max(0, i - 1), i + 1):
+                    print("  ref", r[j, :9], r[j, 9:19])
+                    print("  got", t[j, :9], t[j, 9:16])
+            break
+print("first divergences by (previous element, reference element, our element):", hist)
