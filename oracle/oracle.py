@@ -45,6 +45,7 @@ def lib():
         L.orc_scene_destroy.restype = None
         L.orc_run.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                               C.POINTER(_abi.Tallies)]
+        L.orc_run_reference_order.argtypes = L.orc_run.argtypes
         L.orc_step_tape.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_abi.PhotonSoA), f64p, u64p,
                                     C.c_uint32, C.c_int, f64p]
         L.orc_op_intersect.argtypes = [C.c_void_p, C.c_uint32, f64p, f64p, f64p]
@@ -110,8 +111,10 @@ class OracleScene:
         _check(lib().orc_run(self.handle, seed, first_photon, n_photons, C.byref(t)))
         return _scene.tallies_to_dict(t, arrays)
 
-    def run_threads(self, n_photons, seed=0, first_photon=0, threads=1):
-        """Split the id range over `threads` host threads (ctypes drops the GIL)."""
+    def run_threads(self, n_photons, seed=0, first_photon=0, threads=1, reference_order=False):
+        """Split the id range over `threads` host threads (ctypes drops the GIL).
+        `reference_order`: draw where and how the reference draws (private
+        stream per photon) instead of following the kernels' event layout."""
         from concurrent.futures import ThreadPoolExecutor
         from raytracer_amd.distributed import shard_range
         blocks = [_scene.new_tallies(self.n_elements) for _ in range(threads)]
@@ -119,8 +122,8 @@ class OracleScene:
         def work(i):
             first, cnt = shard_range(n_photons, i, threads)
             if cnt:
-                _check(lib().orc_run(self.handle, seed, first_photon + first, cnt,
-                                     C.byref(blocks[i][0])))
+                fn = lib().orc_run_reference_order if reference_order else lib().orc_run
+                _check(fn(self.handle, seed, first_photon + first, cnt, C.byref(blocks[i][0])))
         with ThreadPoolExecutor(threads) as ex:
             list(ex.map(work, range(threads)))
         total = _scene.tallies_to_dict(*blocks[0])

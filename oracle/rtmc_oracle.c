@@ -357,6 +357,8 @@ typedef struct {
     int overrun;
     uint32_t key[2], pid[2], event;
     uint32_t w[4];
+    uint32_t buf[4], block;
+    int have;
 } rng_t;
 
 static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
@@ -385,19 +387,43 @@ static void rng_event(rng_t *g)
     philox4x32_10(ctr, g->key, g->w);
     g->event++;
 }
-static double tape_next(rng_t *g)
+/* tape_mode 1: the next recorded value, whatever its law.  tape_mode 2
+ * ("reference order"): the draws are made where and how the reference makes
+ * them (three normals for a direction, rejection sampling, ...) but their
+ * values come from a private Philox stream of the photon (counter word 3 =
+ * 0xFFFFFFFF keeps it apart from the event blocks); used to check at scale that
+ * the samplers of the event layout follow the same laws. */
+enum { DRAW_UNIFORM, DRAW_NORMAL, DRAW_EXPONENTIAL };
+static double stream_uniform(rng_t *g)
 {
+    if (g->have == 0) {
+        uint32_t ctr[4] = {g->pid[0], g->pid[1], g->block++, 0xFFFFFFFFu};
+        philox4x32_10(ctr, g->key, g->buf);
+        g->have = 4;
+    }
+    uint32_t a = g->buf[4 - g->have], b = g->buf[5 - g->have];
+    g->have -= 2;
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0; /* 53 bits, as numpy's random_sample */
+}
+static double tape_next(rng_t *g, int law)
+{
+    if (g->tape_mode == 2) {
+        if (law == DRAW_UNIFORM) return stream_uniform(g);
+        if (law == DRAW_EXPONENTIAL) return -log(1.0 - stream_uniform(g));
+        double r = sqrt(-2.0 * log(1.0 - stream_uniform(g)));
+        return r * cos(6.283185307179586 * stream_uniform(g));
+    }
     if (g->pos >= g->end) { g->overrun = 1; return 0.5; }
     return g->tape[g->pos++];
 }
 static double u24(uint32_t w) { return (double)(w >> 8) * (1.0 / 16777216.0); }
-static double rng_uniform(rng_t *g, int slot) { return g->tape_mode ? tape_next(g) : u24(g->w[slot]); }
+static double rng_uniform(rng_t *g, int slot) { return g->tape_mode ? tape_next(g, DRAW_UNIFORM) : u24(g->w[slot]); }
 /* unit-scale exponential: numpy legacy = -log(1 - U) */
-static double rng_exponential(rng_t *g, int slot) { return g->tape_mode ? tape_next(g) : -log(1.0 - u24(g->w[slot])); }
+static double rng_exponential(rng_t *g, int slot) { return g->tape_mode ? tape_next(g, DRAW_EXPONENTIAL) : -log(1.0 - u24(g->w[slot])); }
 /* three standard normals; philox: Box-Muller on (w0,w1) and (w2,w3) */
 static void rng_normal3(rng_t *g, double *o)
 {
-    if (g->tape_mode) { o[0] = tape_next(g); o[1] = tape_next(g); o[2] = tape_next(g); return; }
+    if (g->tape_mode) { for (int j = 0; j < 3; j++) o[j] = tape_next(g, DRAW_NORMAL); return; }
     const double two_pi = 6.283185307179586;
     double r0 = sqrt(-2.0 * log(((double)(g->w[0] >> 8) + 1.0) * (1.0 / 16777216.0)));
     double t0 = two_pi * u24(g->w[1]);
@@ -784,12 +810,12 @@ static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
     const double pi = 3.141592653589793;
     double sx, cx, psi_a, theta, phi, ph = 0, u_pol = 0, u_lambda = 0;
     if (g->tape_mode) {
-        double ux = tape_next(g) * pi, uy = tape_next(g);
-        while (uy > pow(sin(ux), 3) && !g->overrun) { ux = tape_next(g) * pi; uy = tape_next(g); }
-        psi_a = tape_next(g) * 2 * pi;
+        double ux = tape_next(g, DRAW_UNIFORM) * pi, uy = tape_next(g, DRAW_UNIFORM);
+        while (uy > pow(sin(ux), 3) && !g->overrun) { ux = tape_next(g, DRAW_UNIFORM) * pi; uy = tape_next(g, DRAW_UNIFORM); }
+        psi_a = tape_next(g, DRAW_UNIFORM) * 2 * pi;
         sx = sin(ux); cx = cos(ux);
-        theta = M->m.align_S * tape_next(g);
-        phi = tape_next(g) * 2.0 * pi;
+        theta = M->m.align_S * tape_next(g, DRAW_NORMAL);
+        phi = tape_next(g, DRAW_UNIFORM) * 2.0 * pi;
     } else {
         rng_event(g);
         /* F(c) = (2 - 3c + c^3)/4 for c = cos(x); the root of c^3 - 3c + 2 - 4u in [-1, 1] */
@@ -814,7 +840,7 @@ static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
     z_axis_frame(vm, tm);
     if (M->m.abs_em_angle > 0) { /* :139-149 */
         double th = (M->m.abs_em_angle / 180.0) * pi;
-        if (g->tape_mode) ph = tape_next(g) * 2 * pi;
+        if (g->tape_mode) ph = tape_next(g, DRAW_UNIFORM) * 2 * pi;
         double v[3] = {sin(th) * cos(ph), sin(th) * sin(ph), cos(th)};
         double etm[3][3];
         z_axis_frame(v, etm);
@@ -833,7 +859,7 @@ static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
         polarization_random(p, g, p->D);
     else
         perpendicular(p->D, u_pol, p->E);
-    if (g->tape_mode) u_lambda = tape_next(g);
+    if (g->tape_mode) u_lambda = tape_next(g, DRAW_UNIFORM);
     return u_lambda;
 }
 
@@ -854,7 +880,7 @@ static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int 
             /* MonteCarloFRET.py:92-105: direction, wavelength, polarisation */
             if (g->tape_mode) {
                 direction_isotropic(g, p->D);
-                u_lambda = tape_next(g);
+                u_lambda = tape_next(g, DRAW_UNIFORM);
                 polarization_random(p, g, p->D);
             } else
                 emit_philox(p, g);
@@ -880,7 +906,7 @@ static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int 
             if (g->tape_mode) {
                 direction_isotropic(g, p->D);
                 polarization_random(p, g, p->D);
-                u_lambda = tape_next(g);
+                u_lambda = tape_next(g, DRAW_UNIFORM);
             } else
                 emit_philox(p, g);
             p->wl = emit_wavelength(M, 0, u_lambda);
@@ -1174,8 +1200,21 @@ static void count_fate(const ph_t *p, rtmc_tallies *t)
     else t->n_capped++;
 }
 
-/* RayTrace.py:166-201 for photon ids [first, first+n) */
+static int run_ids(const orc_scene *s, uint64_t seed, uint64_t first, uint64_t n, rtmc_tallies *out, int mode);
+
+/* RayTrace.py:166-201 for photon ids [first, first+n), event layout of the HIP kernels */
 ORC_EXPORT int orc_run(const orc_scene *s, uint64_t seed, uint64_t first, uint64_t n, rtmc_tallies *out)
+{
+    return run_ids(s, seed, first, n, out, 0);
+}
+
+/* the same photons with every draw made where and how the reference makes it */
+ORC_EXPORT int orc_run_reference_order(const orc_scene *s, uint64_t seed, uint64_t first, uint64_t n, rtmc_tallies *out)
+{
+    return run_ids(s, seed, first, n, out, 2);
+}
+
+static int run_ids(const orc_scene *s, uint64_t seed, uint64_t first, uint64_t n, rtmc_tallies *out, int mode)
 {
     if (!s || !out || out->n_elements != s->n_el) {
         snprintf(g_err, sizeof g_err, "bad arguments");
@@ -1187,6 +1226,7 @@ ORC_EXPORT int orc_run(const orc_scene *s, uint64_t seed, uint64_t first, uint64
         memset(&g, 0, sizeof g);
         g.key[0] = (uint32_t)seed; g.key[1] = (uint32_t)(seed >> 32);
         g.pid[0] = (uint32_t)id; g.pid[1] = (uint32_t)(id >> 32);
+        g.tape_mode = mode;
         ph_t p;
         memset(&p, 0, sizeof p);
         launch_photon(s, &p, &g);

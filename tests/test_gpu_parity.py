@@ -221,6 +221,26 @@ def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     assert abs(eta_ref - eta_gpu) <= 3 * _sigma(n_ref, eta_gpu) / n_ref * (1 + n_ref / n_gpu) ** 0.5
 
 
+@pytest.mark.parametrize("name", ["C2", "C3", "C6", "C7"])
+def test_production_tallies_against_reference_order_sampling_at_scale(scenes, oracle_mod, name):
+    """A sharper version of the 3-sigma test: 2e7 float32 GPU photons against
+    4e6 photons of the CPU checker drawing where and how the reference draws
+    (the mode pinned by the tape replays).  Every detector count, the internal
+    conversions and the absorbed-once count agree within 4.5 sigma, i.e. to a
+    few 1e-4 of the photon number."""
+    rt, s = scenes(name)
+    n_gpu, n_cpu = 20000000, 4000000
+    gpu = s.run(n_gpu, seed=99)
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n_cpu, seed=7, threads=16,
+                                                               reference_order=True)
+    pairs = [(gpu["counter"][i], cpu["counter"][i]) for i in range(s.n_elements)]
+    pairs += [(gpu[k], cpu[k]) for k in ("n_internal_converted", "n_absorbed_once")]
+    for x, y in pairs:
+        pg, pc = float(x) / n_gpu, float(y) / n_cpu
+        sig = max((pg * (1 - pg) * (1.0 / n_gpu + 1.0 / n_cpu)) ** 0.5, 1.0 / n_cpu)
+        assert abs(pg - pc) <= 4.5 * sig, (name, pg, pc, sig)
+
+
 def test_results_do_not_depend_on_batching(scenes):
     """Photon ids key the variates: one call of 60000 ids equals three calls of 20000."""
     rt, s = scenes("C3")

@@ -1,0 +1,64 @@
+"""Throughput, path statistics and optical-efficiency deltas for every parity
+configuration, one GPU; prints a markdown table.
+
+usage: python tools/results_table.py [photons_per_config]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import helpers as H  # noqa: E402
+from raytracer_amd import configs  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+PEAK = 157.3e12
+n_default = float(sys.argv[1]) if len(sys.argv) > 1 else 1e8
+rows = []
+for name in ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"]:
+    rt = H.raytrace_for(name)
+    s = rt.Scene()
+    n = int(n_default if name not in ("C1_open", "C8") else n_default / 50)
+    s.run(min(n, 1000000), seed=3)                      # warm-up, scene upload
+    t0 = time.perf_counter()
+    t = s.run(n, seed=7)
+    wall = time.perf_counter() - t0
+    ms = s.last_kernel_ms()
+    n_el = s.n_elements
+    edges = [i for i, oe in enumerate(rt.OpticalElements)
+             if oe.Type.kind == "Dump" and i < n_el - 6] if name != "C1_open" else [2, 3, 4, 5]
+    eta = float(t["counter"][edges].sum()) / n
+    flops = t["n_steps"] * (61 * n_el + 250)
+    ref = H.ref_tallies(name)
+    d_sigma = None
+    eta_ref = None
+    if ref:
+        n_ref = sum(r["n"] for r in ref)
+        c_ref = np.sum([r["counter"] for r in ref], axis=0)
+        eta_ref = float(c_ref[edges].sum()) / n_ref
+        sig = max(1.0, (n_ref * eta * (1 - eta)) ** 0.5) / n_ref
+        d_sigma = (eta - eta_ref) / sig
+    o = oracle.OracleScene.from_raytrace(rt)
+    n_cpu = max(1000, int(min(n, 4e6 if name not in ("C1_open", "C8") else 4e4)))
+    t1 = time.perf_counter()
+    c = o.run_threads(n_cpu, seed=7, threads=16)
+    cpu_rate = n_cpu / (time.perf_counter() - t1)
+    rows.append(dict(config=name, n=n, photons_per_s=n / (ms * 1e-3), wall_photons_per_s=n / wall,
+                     steps_per_photon=t["n_steps"] / n, eta=eta, eta_ref=eta_ref, d_sigma=d_sigma,
+                     valu_frac=flops / (ms * 1e-3) / PEAK, hbm_frac=n * 96 / (ms * 1e-3) / 8e12,
+                     ic=t["n_internal_converted"] / n, capped=t["n_capped"] / n, n_el=n_el,
+                     cpu_photons_per_s=cpu_rate, cpu_eta=float(c["counter"][edges].sum()) / n_cpu))
+    print(json.dumps(rows[-1]), flush=True)
+print()
+print("| config | elements | N (GPU) | GPU photons/s (kernel) | steps/photon | eta (edge detectors) | eta reference | delta (sigma of the reference sample) | FP32-VALU frac | HBM frac | oracle, 16 threads, photons/s |")
+print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
+for r in rows:
+    print("| %s | %d | %.0e | %.3g | %.2f | %.5f | %s | %s | %.3f | %.4f | %.3g |" % (
+        r["config"], r["n_el"], r["n"], r["photons_per_s"], r["steps_per_photon"], r["eta"],
+        "%.5f" % r["eta_ref"] if r["eta_ref"] is not None else "-",
+        "%+.2f" % r["d_sigma"] if r["d_sigma"] is not None else "-",
+        r["valu_frac"], r["hbm_frac"], r["cpu_photons_per_s"]))
