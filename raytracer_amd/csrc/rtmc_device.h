@@ -68,10 +68,14 @@ struct HitRec {
     int32_t pad[sizeof(real) == 4 ? 2 : 5];
 };
 
-// The search reads the table four records at a time (one or two wide scalar
-// loads, one wait); every axis group is padded to a multiple of four with
-// records that can never be hit (negative half extents).
-constexpr int HIT_CHUNK = 4;
+// The search reads the table two records at a time (one 64-byte scalar load,
+// one wait); every axis group is padded to a multiple of two with records that
+// can never be hit (negative half extents).  Four at a time halves the number
+// of waits but keeps 32 SGPRs busy, which the allocator pays for with spills.
+#ifndef RTMC_HIT_CHUNK
+#define RTMC_HIT_CHUNK 2
+#endif
+constexpr int HIT_CHUNK = RTMC_HIT_CHUNK;
 template <typename real>
 struct alignas(64) HitChunk {
     HitRec<real> r[HIT_CHUNK];
@@ -903,7 +907,7 @@ __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real 
     best.e = ok ? index : best.e;
 }
 
-// One group of axis-aligned rectangles, four records per scalar fetch.
+// One group of axis-aligned rectangles, one chunk of records per scalar fetch.
 template <typename real>
 __device__ __forceinline__ void scan_axis_group(const HitChunk<real> *chunks, int count, real inv_dk, real m_lk,
                                                 real Li, real Di, real Lj, real Dj, real adm_q, bool adm_all,
@@ -1183,12 +1187,14 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
             tally.bounce(el_idx);
         }
-        // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old)
+        // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old),
+        // i.e. by the smallest rotation that takes a = D_old/|D_old| to b = D_new/|D_new|:
+        //   R E = E - s (s.E)/h + 2 b (a.E),  s = a + b,  h = s.s/2 = 1 + a.b
+        // (no rotation when a = -b: the reference finds a zero cross product there).
+        // For the line-based reflection s = 2 (n.a) n exactly, which keeps grazing
+        // reflections (a close to -b) as accurate as any other.
 #ifndef RTMC_ABLATE_ROTATE
-        {
-            if (!have_axis) {
-                cx = p.Dy * oDz - p.Dz * oDy; cy = p.Dz * oDx - p.Dx * oDz; cz = p.Dx * oDy - p.Dy * oDx;
-            }
+        if (SHAPES && have_axis) {  // lens: Rodrigues form about the known axis
             real c2n = cx * cx + cy * cy + cz * cz;
             if (c2n != real(0)) {
                 real nn = p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz;
@@ -1204,6 +1210,23 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
                     normalize3(ex, ey, ez);
                     p.Ex = ex; p.Ey = ey; p.Ez = ez;
                 }
+            }
+        } else {
+            const real ia = M<real>::rcp(dnorm);
+            const real ib = M<real>::rsqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+            const real k = real(2) * dn * ia;
+            const real sx = reflect ? k * nx : oDx * ia + p.Dx * ib;
+            const real sy = reflect ? k * ny : oDy * ia + p.Dy * ib;
+            const real sz = reflect ? k * nz : oDz * ia + p.Dz * ib;
+            const real h = real(0.5) * (sx * sx + sy * sy + sz * sz);
+            if (h > real(0)) {
+                const real se = (sx * p.Ex + sy * p.Ey + sz * p.Ez) * M<real>::rcp(h);
+                const real ae = real(2) * (oDx * p.Ex + oDy * p.Ey + oDz * p.Ez) * (ia * ib);
+                real ex = p.Ex - sx * se + p.Dx * ae;
+                real ey = p.Ey - sy * se + p.Dy * ae;
+                real ez = p.Ez - sz * se + p.Dz * ae;
+                normalize3(ex, ey, ez);
+                p.Ex = ex; p.Ey = ey; p.Ez = ez;
             }
         }
 #endif
