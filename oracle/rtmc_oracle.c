@@ -18,7 +18,7 @@
  *
  * Two variate sources:
  *   tape   -- the values the reference drew, in its order;
- *   philox -- Philox4x32-10, key = seed, counter = (photon id, event, 0): the
+ *   philox -- Philox4x32-10, key = seed, counter = (photon id, iteration, purpose): the
  *             same stream layout as the HIP kernels (csrc/rtmc_device.h), so a
  *             GPU run and an oracle run of the same seed follow the same
  *             photons.
@@ -355,7 +355,7 @@ typedef struct {
     const double *tape;
     uint64_t pos, end;
     int overrun;
-    uint32_t key[2], pid[2], event;
+    uint32_t key[2], pid[2];
     uint32_t w[4];
     uint32_t buf[4], block;
     int have;
@@ -379,13 +379,18 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 }
 ORC_EXPORT void orc_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
 
-/* start a new draw event: in philox mode one fresh block of four words */
-static void rng_event(rng_t *g)
+/* philox mode: the block of four words for (loop iteration, purpose), laid out
+ * as in csrc/rtmc_device.h: purpose 0 = the iteration's own block (interface,
+ * detector, absorption), r = r-th back transfer of that absorption,
+ * BLK_EMIT (+1) = re-emission, BLK_LAUNCH = launch */
+#define BLK_STEP 0u
+#define BLK_EMIT 0x80000000u
+#define BLK_LAUNCH 0xC0000000u
+static void rng_block(rng_t *g, uint32_t iter, uint32_t purpose)
 {
     if (g->tape_mode) return;
-    uint32_t ctr[4] = {g->pid[0], g->pid[1], g->event, 0};
+    uint32_t ctr[4] = {g->pid[0], g->pid[1], iter, purpose};
     philox4x32_10(ctr, g->key, g->w);
-    g->event++;
 }
 /* tape_mode 1: the next recorded value, whatever its law.  tape_mode 2
  * ("reference order"): the draws are made where and how the reference makes
@@ -528,7 +533,7 @@ static void launch_photon(const orc_scene *s, ph_t *p, rng_t *g)
     const rtmc_source *src = &s->src;
     p->was_element = 0;
     memcpy(p->L, src->location, sizeof p->L);
-    rng_event(g); /* philox: one event for the whole launch: words 0,1 direction, 2 polarisation, 3 wavelength */
+    rng_block(g, 0, BLK_LAUNCH); /* philox: one block for the whole launch: words 0,1 direction, 2 polarisation, 3 wavelength */
     if (src->direction_mode == 1) {
         double d[3];
         if (g->tape_mode) direction_isotropic(g, d);
@@ -790,7 +795,7 @@ static double emit_wavelength(const omat_t *M, int donor, double u)
 /* philox mode: the re-emission event, words 0,1 direction, 2 polarisation, 3 free path */
 static void emit_philox(ph_t *p, rng_t *g)
 {
-    rng_event(g);
+    rng_block(g, (uint32_t)p->iter, BLK_EMIT);
     sphere_direction(u24(g->w[0]), u24(g->w[1]), p->D);
     perpendicular(p->D, u24(g->w[2]), p->E);
 }
@@ -817,7 +822,7 @@ static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
         theta = M->m.align_S * tape_next(g, DRAW_NORMAL);
         phi = tape_next(g, DRAW_UNIFORM) * 2.0 * pi;
     } else {
-        rng_event(g);
+        rng_block(g, (uint32_t)p->iter, BLK_EMIT);
         /* F(c) = (2 - 3c + c^3)/4 for c = cos(x); the root of c^3 - 3c + 2 - 4u in [-1, 1] */
         cx = 2.0 * cos((acos(2.0 * u24(g->w[0]) - 1.0) + 4.0 * pi) / 3.0);
         double s2 = 1.0 - cx * cx;
@@ -825,7 +830,7 @@ static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
         psi_a = 2 * pi * u24(g->w[1]);
         double r = sqrt(-2.0 * log(((double)(g->w[2] >> 8) + 1.0) * (1.0 / 16777216.0)));
         theta = M->m.align_S * (r * cos(2 * pi * u24(g->w[3])));
-        rng_event(g);
+        rng_block(g, (uint32_t)p->iter, BLK_EMIT + 1u);
         phi = 2 * pi * u24(g->w[0]);
         ph = 2 * pi * u24(g->w[1]);
         u_pol = u24(g->w[2]);
@@ -869,9 +874,10 @@ static double aligned_acceptor_emission(const orc_scene *s, ph_t *p, rng_t *g)
 static void fret_event(const orc_scene *s, ph_t *p, rng_t *g, int in_donor, int have_block)
 {
     omat_t *M = &s->mat[p->mat];
+    uint32_t round = 0;
     for (;;) {
         double u_lambda = 0;
-        if (!have_block) rng_event(g);
+        if (!have_block) rng_block(g, (uint32_t)p->iter, BLK_STEP + (++round));
         if (!g->tape_mode) u_lambda = u24(g->w[3]); /* saved before later events replace the block */
         have_block = 0;
         /* MonteCarloFRET.py:90 -- drawn even when the acceptor was excited */
@@ -943,7 +949,6 @@ static void check_absorption(const orc_scene *s, ph_t *p, rng_t *g, const double
             double b_d = M->m.conc_b * 1e-3 * log(10.0) * M->m.emax_D * fmax(1e-99, ed);
             double b_a = M->m.conc_a * 1e-3 * log(10.0) * M->m.emax_A * fmax(1e-99, ea);
             if (M->m.is_aligned) b_a *= p->psi * 3; /* :238-241 */
-            rng_event(g);
             int in_donor = rng_uniform(g, 0) < b_d / (b_d + b_a);
             fret_event(s, p, g, in_donor, 1);
             p->absorbed_now = 1;
@@ -1063,7 +1068,6 @@ static void interface_op(const orc_scene *s, ph_t *p, rng_t *g, int el, rtmc_tal
     prepare_execution(p);
     int other = (s->mat[p->mat].m.name_id == s->mat[e->material1].m.name_id) ? e->material2 : e->material1;
     double n1 = s->mat[p->mat].m.n, n2 = s->mat[other].m.n;
-    rng_event(g);
     if (is_total_reflect(p, n1, n2)) {
         reflect_on_plane(p);
         p->reflected = 1;
@@ -1133,7 +1137,6 @@ static void dump_op(const orc_scene *s, ph_t *p, rng_t *g, int el, rtmc_tallies 
     int counted = 1;
     if (e->eqe_table >= 0) {
         const tab_t *q = &s->eqe[e->eqe_table];
-        rng_event(g);
         counted = q->y[find_closest(q->x, q->len, p->wl)] > rng_uniform(g, 0);
     }
     if (t) {
@@ -1164,6 +1167,7 @@ static void dump_op(const orc_scene *s, ph_t *p, rng_t *g, int el, rtmc_tallies 
 /* one iteration of the loop body, RayTrace.py:178-195; returns 0 when the photon stops */
 static int loop_iteration(const orc_scene *s, ph_t *p, rng_t *g, rtmc_tallies *t)
 {
+    rng_block(g, (uint32_t)p->iter, BLK_STEP); /* philox: this iteration's variates */
     find_crossing(s, p);
     p->stale = !isfinite(p->smallest);
     p->absorbed_now = 0;

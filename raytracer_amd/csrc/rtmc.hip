@@ -87,6 +87,10 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // Philox event and one pass through the direction / polarisation samplers.
 // The grid is sized to the machine, not to n.
 enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
+#ifndef RTMC_RENEW_THRESHOLD
+#define RTMC_RENEW_THRESHOLD 32
+#endif
+constexpr int RENEW_THRESHOLD = RTMC_RENEW_THRESHOLD;  // lanes (of 64) that must be waiting
 
 // Register budget: the float32 kernels are held to 80 VGPRs so that six waves
 // share a SIMD (three 512-thread workgroups per CU); the loop waits on LDS
@@ -116,24 +120,38 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     Photon<real> p;
     Rng<real, false> g;
     g.k0 = (uint32_t)seed; g.k1 = (uint32_t)(seed >> 32);
-    g.id0 = g.id1 = g.ev = 0;
+    g.id0 = g.id1 = 0;
     int need = NEED_LAUNCH;
     uint64_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;
     const uint32_t lane = threadIdx.x & 63;
 
+#ifdef RTMC_PROFILE_SECTIONS
+    unsigned long long cyc_renew = 0, cyc_step = 0, n_renew = 0, n_step = 0, lanes_renew = 0, lanes_step = 0;
+#define SECTION_BEGIN() const unsigned long long sec_t0 = __builtin_readcyclecounter()
+#define SECTION_END(acc, cnt, lanes, mask) do { acc += __builtin_readcyclecounter() - sec_t0; cnt++; lanes += __popcll(mask); } while (0)
+#else
+#define SECTION_BEGIN() do {} while (0)
+#define SECTION_END(acc, cnt, lanes, mask) do {} while (0)
+#endif
     for (;;) {
-        if (__ballot(need == NEED_LAUNCH || need == NEED_EMIT) != 0ull) {
+        // The renew block costs about half a loop iteration whatever the number of
+        // lanes in it; it waits until enough lanes want it (or nobody can step).
+        const unsigned long long want = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
+        if (want != 0ull && (__popcll(want) >= RENEW_THRESHOLD || __ballot(need == NEED_NONE) == 0ull)) {
+            SECTION_BEGIN();
+#ifdef RTMC_PROFILE_SECTIONS
+            const unsigned long long renew_mask = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
+#endif
             // (a) absorbed photons: donor/acceptor coin and pathway (PhotonObject.py:244,
             //     MonteCarloFRET.py:63-193); one event, a back transfer opens another
             bool emitting = false;
             if (need == NEED_EMIT) {
                 const DevMat<real> &m = lds.mats[p.mat];
                 const DevAbs<real> &a = lds.abs[m.abs_slot * hot.n_wid + p.wid];
-                g.event();
                 const bool in_donor = absorbed_by_donor<ALIGNED>(m, a, p, g);
                 uint32_t v_lambda;
-                const int outcome = fret_decide(m, g, in_donor, v_lambda);
+                const int outcome = fret_decide(m, g, in_donor, (uint32_t)p.iter, v_lambda);
                 if (outcome == 1) {
                     p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, v_lambda);
                     p.status = RTMC_ST_REEMITTED_DONOR;
@@ -168,7 +186,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                     const uint32_t rank = lanes_below(idle);
                     if (need == NEED_LAUNCH && rank < avail) {
                         const uint64_t id = first + chunk_next + rank;
-                        g.id0 = (uint32_t)id; g.id1 = (uint32_t)(id >> 32); g.ev = 0;
+                        g.id0 = (uint32_t)id; g.id1 = (uint32_t)(id >> 32);
                         launching = true;
                     }
                     const uint32_t want = (uint32_t)__popcll(idle);
@@ -178,23 +196,30 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             if (exhausted && need == NEED_LAUNCH) need = NEED_OFF;
             // (c) one event for both: direction, polarisation, free path / wavelength
             if (launching | emitting) {
-                g.event();
+                // an emitting photon's iteration count has already moved on
+                const uint32_t emit_iter = (uint32_t)p.iter - 1u;
+                g.block(launching ? 0u : emit_iter, launching ? BLK_LAUNCH : BLK_EMIT);
                 if (launching) {
                     renew_launch(sc, lds, p, g);
                 } else {
                     const DevMat<real> &m = lds.mats[p.mat];
                     if (ALIGNED && (m.flags & 2) && p.status == RTMC_ST_REEMITTED_ACCEPTOR)
-                        renew_emit_aligned(hot, lds, m, p, g);
+                        renew_emit_aligned(hot, lds, m, p, g, emit_iter);
                     else
                         renew_emit<ALIGNED>(hot, lds, m, p, g);
                 }
                 need = NEED_NONE;
             }
+            SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);
         }
         if (__ballot(need == NEED_NONE) == 0ull) {
             if (__ballot(need != NEED_OFF) == 0ull) break;
             continue;
         }
+        SECTION_BEGIN();
+#ifdef RTMC_PROFILE_SECTIONS
+        const unsigned long long step_mask = __ballot(need == NEED_NONE);
+#endif
         if (need == NEED_NONE) {
             const StepResult r = photon_step<FEATURES>(hot, lds, p, g, tally);
             if (r == STEP_ENDED) {
@@ -204,7 +229,14 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 need = NEED_EMIT;
             }
         }
+        SECTION_END(cyc_step, n_step, lanes_step, step_mask);
     }
+#ifdef RTMC_PROFILE_SECTIONS
+    if (lane == 0) {  // per-wave totals behind the work counter
+        atomicAdd(&work[8], cyc_renew); atomicAdd(&work[9], n_renew); atomicAdd(&work[10], lanes_renew);
+        atomicAdd(&work[11], cyc_step); atomicAdd(&work[12], n_step); atomicAdd(&work[13], lanes_step);
+    }
+#endif
 
     // flush: per-lane totals into LDS, then the workgroup's accumulators to HBM
     if (tally.lane_steps) atomicAdd(&lds.acc[ACC_STEPS], tally.lane_steps);
@@ -1035,7 +1067,11 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
         fprintf(stderr, "[rtmc] trace launch: %u workgroups of %d threads (%d per CU x %d CUs), %zu B LDS, %llu photons\n",
                 grid, TRACE_BLOCK, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
     HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
+#ifdef RTMC_PROFILE_SECTIONS
+    HIP_TRY(hipMemsetAsync(p.work, 0, 128, p.stream));
+#else
     HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
+#endif
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
     {
         const void *scene_ptr = f32 ? p.scene32 : p.scene64;
@@ -1052,6 +1088,17 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, p.ev0, p.ev1));
     p.last_ms = ms;
+#ifdef RTMC_PROFILE_SECTIONS
+    {
+        unsigned long long w[16];
+        HIP_TRY(hipMemcpy(w, p.work, sizeof w, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[rtmc] sections: renew %llu passes, %.0f cycles each, %.1f lanes; step %llu passes, %.0f cycles each, %.1f lanes; "
+                        "renew share of wave time %.3f\n",
+                w[9], (double)w[8] / (double)std::max(1ull, w[9]), (double)w[10] / (double)std::max(1ull, w[9]),
+                w[12], (double)w[11] / (double)std::max(1ull, w[12]), (double)w[13] / (double)std::max(1ull, w[12]),
+                (double)w[8] / (double)(w[8] + w[11]));
+    }
+#endif
 
     const unsigned long long *sc = host.data();
     const unsigned long long *bounce = sc + ACC_SCALARS, *spectral = bounce + s->n_el,

@@ -250,28 +250,37 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// A draw *event* is one place of the photon's life where variates are needed
-// (launch, one interface operation, one absorption, one re-emission, ...).  In
-// Philox mode every event owns one counter value, i.e. four fresh 32-bit
-// words; a word is used as a 24-bit uniform k/2^24.  In tape mode the values
-// are read sequentially in the order the reference draws them.
+// Philox mode: variates come in blocks of four 32-bit words, one block per
+// counter value (photon id lo, hi, loop iteration, purpose); a word is used as
+// a 24-bit uniform k/2^24.
+//   purpose 0          the iteration's own block, computed for every photon at
+//                      the top of the iteration and used by whatever happens in
+//                      it: interface [Fresnel test, free path on crossing],
+//                      detector [detection test], absorption [donor/acceptor
+//                      coin, donor pathway, acceptor pathway, wavelength]
+//   purpose r = 1, 2.. the r-th back transfer acceptor -> donor of that absorption
+//   BLK_EMIT (+1)      re-emission after that absorption [direction, direction,
+//                      polarisation, free path] (aligned acceptors: two blocks)
+//   BLK_LAUNCH         launch (iteration 0) [direction, direction, polarisation, wavelength]
+// In tape mode the values are read sequentially in the order the reference
+// draws them.
+enum : uint32_t { BLK_STEP = 0u, BLK_EMIT = 0x80000000u, BLK_LAUNCH = 0xC0000000u };
 template <typename real, bool TAPE>
 struct Rng;
 
 template <typename real>
 struct Rng<real, false> {
-    uint32_t k0, k1, id0, id1, ev;
+    uint32_t k0, k1, id0, id1;
     uint32_t w[4];
-    __device__ __forceinline__ void skip() { ev++; }
 #ifdef RTMC_ABLATE_PHILOX
-    __device__ __forceinline__ void event()
+    __device__ __forceinline__ void block(uint32_t iter, uint32_t purpose)
     {
-        uint32_t h = id0 * 0x9E3779B9u + ev * 0x85EBCA6Bu + k0;
+        uint32_t h = id0 * 0x9E3779B9u + (iter ^ purpose) * 0x85EBCA6Bu + k0;
         h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-        w[0] = h; w[1] = h * 0x297A2D39u; w[2] = h ^ 0xA5A5A5A5u; w[3] = h * 0x9E3779B9u; ev++;
+        w[0] = h; w[1] = h * 0x297A2D39u; w[2] = h ^ 0xA5A5A5A5u; w[3] = h * 0x9E3779B9u;
     }
 #else
-    __device__ __forceinline__ void event() { philox4x32_10(id0, id1, ev, 0u, k0, k1, w); ev++; }
+    __device__ __forceinline__ void block(uint32_t iter, uint32_t purpose) { philox4x32_10(id0, id1, iter, purpose, k0, k1, w); }
 #endif
     // the uniform as an integer: floor(u * 2^32)
     __device__ __forceinline__ uint32_t u32(int slot) { return w[slot] & 0xFFFFFF00u; }
@@ -292,8 +301,7 @@ struct Rng<real, true> {
         if (pos >= end) { overrun = true; return 0.5; }
         return tape[pos++];
     }
-    __device__ __forceinline__ void skip() {}
-    __device__ __forceinline__ void event() {}
+    __device__ __forceinline__ void block(uint32_t, uint32_t) {}
     __device__ __forceinline__ uint32_t u32(int)
     {
         double v = next() * 4294967296.0;
@@ -519,19 +527,19 @@ __device__ __forceinline__ void launch_in_reference_order(SceneArg<real> sc, con
 }
 
 // MonteCarloFRET.py:63-193 RunSimulation, pathway choice for isotropic
-// (non-aligned) dyes.  Word use of the absorption event's block: 0 coin
-// (already consumed), 1 donor pathway, 2 acceptor pathway, 3 wavelength; a
-// back transfer opens a new event.  Returns 0: internal conversion,
+// (non-aligned) dyes.  Word use of the iteration's block: 0 coin (already
+// consumed), 1 donor pathway, 2 acceptor pathway, 3 wavelength; a back
+// transfer opens the next block of this iteration.  Returns 0: internal conversion,
 // 1: donor fluoresces, 2: acceptor fluoresces; `v_lambda` is the wavelength
 // uniform in Philox mode (in tape mode it is drawn later, in reference order).
 template <typename real, bool TAPE>
 __device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE> &g, bool in_donor,
-                                           uint32_t &v_lambda)
+                                           uint32_t iter, uint32_t &v_lambda)
 {
-    bool have_block = true;
+    uint32_t round = 0u;
     for (;;) {
-        if (!have_block) g.event();
-        have_block = false;
+        if (round) g.block(iter, BLK_STEP + round);
+        round++;
         v_lambda = TAPE ? 0u : g.u32(3);
         // MonteCarloFRET.py:90: drawn also when the acceptor absorbed
         uint32_t v = g.u32(1);
@@ -610,7 +618,7 @@ __device__ __forceinline__ void emit_in_reference_order(const HotScene<real> &sc
     const DevAbs<real> &a = lds.abs[m.abs_slot * sc.n_wid + p.wid];
     bool in_donor = absorbed_by_donor<true>(m, a, p, g);  // PhotonObject.py:244
     uint32_t v_lambda;
-    int outcome = fret_decide(m, g, in_donor, v_lambda);
+    int outcome = fret_decide(m, g, in_donor, 0u, v_lambda);
     if (outcome == 2 && (m.flags & 2)) {  // MonteCarloFRET.py:124-162
         const DevOrient<real> &o = lds.orient[p.mat];
         real sx, cx, s_az, c_az, s_phi, c_phi, s_ph = real(0), c_ph = real(1);
@@ -706,7 +714,7 @@ __device__ __forceinline__ void renew_emit(const HotScene<real> &sc, const Lds<r
 }
 
 // Fluorescence of an aligned acceptor (MonteCarloFRET.py:124-162) with two
-// events.  The first (already opened by the caller): word 0 polar angle of the
+// blocks.  The first (already computed by the caller): word 0 polar angle of the
 // emission about the dipole through the closed-form inverse of the sin^3
 // distribution function F(c) = (2 - 3c + c^3)/4, c = cos(angle) -- the reference
 // samples the same law by rejection (RTUtils.py:64-68) --, word 1 its azimuth,
@@ -714,7 +722,8 @@ __device__ __forceinline__ void renew_emit(const HotScene<real> &sc, const Lds<r
 // word 0 tilt azimuth, 1 emission-dipole azimuth, 2 polarisation angle, 3 free path.
 template <typename real>
 __device__ __forceinline__ void renew_emit_aligned(const HotScene<real> &sc, const Lds<real> &lds,
-                                                   const DevMat<real> &m, Photon<real> &p, Rng<real, false> &g)
+                                                   const DevMat<real> &m, Photon<real> &p, Rng<real, false> &g,
+                                                   uint32_t iter)
 {
     const DevOrient<real> &o = lds.orient[p.mat];
     const real pi = real(3.141592653589793);
@@ -726,7 +735,7 @@ __device__ __forceinline__ void renew_emit_aligned(const HotScene<real> &sc, con
     const real r = M<real>::sqrt(real(-2) * M<real>::log((real(g.w[2] >> 8) + real(1)) * real(1.0 / 16777216.0)));
     M<real>::sincos_turns(g.uniform(3), &s_g, &c_g);
     const real tilt = o.S * (r * c_g);
-    g.event();
+    g.block(iter, BLK_EMIT + 1u);
     M<real>::sincos_turns(g.uniform(0), &s_phi, &c_phi);
     M<real>::sincos_turns(g.uniform(1), &s_ph, &c_ph);
     if (!aligned_emission(o, sx, cx, s_az, c_az, tilt, s_phi, c_phi, s_ph, c_ph, p))
@@ -982,6 +991,9 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
 {
     constexpr bool ALIGNED = (FEATURES & FEAT_ALIGNED) != 0;
     constexpr bool SHAPES = (FEATURES & FEAT_SHAPES) != 0;
+    // the variates of this iteration (every lane computes its block together;
+    // which words are used depends on what the iteration turns out to be)
+    g.block((uint32_t)p.iter, BLK_STEP);
     // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
     // Candidates are ordered by |t| (the line parameter); the distance is
     // |t| |D|.  Admissibility: see set_admissibility.  The element the photon
@@ -1102,7 +1114,6 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             bool counted = true;
             const int eqe = (info & 0xFF) - 1;
             if (eqe >= 0) {
-                g.event();
                 counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
             }
             tally.dump(el_idx, info >> 8, p.wid, p.wid0, counted);
@@ -1143,8 +1154,6 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
             const real cn = c * M<real>::rcp(dnorm);
             const bool tir = (n1 > n2) & (cn * cn < real(1) - (n2 * n2) * M<real>::rcp(n1 * n1));
-            // the operation owns one draw event whether or not it needs variates
-            if (tir) g.skip(); else g.event();
             if (!tir) {
                 // Elements.py:84-109 Reflectance, with cos/sin taken algebraically
                 real st2 = r * r * (real(1) - c * c);

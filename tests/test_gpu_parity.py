@@ -186,9 +186,11 @@ def test_f32_follows_f64_photon_for_photon(scenes, name):
     moved = int(np.abs(a["counter"].astype(np.int64) - b["counter"].astype(np.int64)).sum())
     moved += abs(int(a["n_internal_converted"]) - int(b["n_internal_converted"]))
     assert moved <= n // 50000, moved
-    # C8: a photon trapped in the rod until the iteration cap in one precision
-    # and released a little earlier in the other shifts the total by up to 1e4
-    assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= (n // 2000 if name != "C8" else int(b["n_steps"]) // 1000)
+    # a photon that is trapped (between the mirrors of C4, in the rod of C8)
+    # until the iteration cap in one precision and gets out earlier in the
+    # other shifts the total by up to 1e4
+    slack = 10001 * (1 + abs(int(a["n_capped"]) - int(b["n_capped"]))) if name in ("C4", "C8") else 0
+    assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= n // 2000 + slack + (int(b["n_steps"]) // 1000 if name == "C8" else 0)
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C1_open"])
