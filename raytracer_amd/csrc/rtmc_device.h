@@ -188,7 +188,9 @@ template <typename real> struct M;
 template <> struct M<float> {
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
-    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    // v_sqrt_f32 (1 ulp) without the correctly-rounded fix-up sequence
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float sqrt_rn(float x) { return __builtin_sqrtf(x); }  // correctly rounded
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float log(float x) { return ::logf(x); }
     static __device__ __forceinline__ void sincospi(float x, float *s, float *c) { ::sincospif(x, s, c); }
@@ -213,6 +215,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / __builtin_sqrt(x); }
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+    static __device__ __forceinline__ double sqrt_rn(double x) { return __builtin_sqrt(x); }
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ void sincospi(double x, double *s, double *c) { ::sincospi(x, s, c); }
@@ -843,7 +846,7 @@ __device__ __forceinline__ bool cylinder_hit(const DevElem<real> &e, real Lx, re
     const real a3 = qx * qx + qy * qy + qz * qz - e.c1;
     const real dsc = a2 * a2 - real(4) * a1 * a3;
     const bool any = (a1 != real(0)) & ((dsc >= real(0)) | (!M<real>::has_self_hit_eps & sitting));
-    const real sq = M<real>::sqrt(dsc > real(0) ? dsc : real(0));
+    const real sq = M<real>::sqrt_rn(dsc > real(0) ? dsc : real(0));  // a grazing hit amplifies every rounding
     const real inv = M<real>::rcp(real(2) * a1);
     real t1 = (-a2 + sq) * inv, t2 = (-a2 - sq) * inv;
     if (!M<real>::has_self_hit_eps && sitting) {
