@@ -68,6 +68,7 @@ __device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char 
     l.orient = reinterpret_cast<const DevOrient<real> *>(smem + sc.lay.orient);
     l.abs = reinterpret_cast<const DevAbs<real> *>(smem + sc.lay.abs);
     l.cdf = reinterpret_cast<const uint32_t *>(smem + sc.lay.cdf);
+    l.guide = reinterpret_cast<const uint16_t *>(smem + sc.lay.guide);
     l.fx = reinterpret_cast<const uint32_t *>(smem + sc.lay.fx);
     l.bin = reinterpret_cast<const uint16_t *>(smem + sc.lay.bin);
     l.acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
@@ -153,10 +154,10 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 uint32_t v_lambda;
                 const int outcome = fret_decide(m, g, in_donor, (uint32_t)p.iter, v_lambda);
                 if (outcome == 1) {
-                    p.wid = m.widD_off + cdf_pick(lds.cdf + m.cdfD_off, m.cdfD_len, v_lambda);
+                    p.wid = m.widD_off + cdf_pick_guided(lds.cdf + m.cdfD_off, m.cdfD_len, lds.guide + m.gD_off, v_lambda);
                     p.status = RTMC_ST_REEMITTED_DONOR;
                 } else if (outcome == 2) {
-                    p.wid = m.widA_off + cdf_pick(lds.cdf + m.cdfA_off, m.cdfA_len, v_lambda);
+                    p.wid = m.widA_off + cdf_pick_guided(lds.cdf + m.cdfA_off, m.cdfA_len, lds.guide + m.gA_off, v_lambda);
                     p.status = RTMC_ST_REEMITTED_ACCEPTOR;
                 } else {
                     p.status = RTMC_ST_INTERNAL_CONVERTED;
@@ -646,6 +647,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.cdfD_off = cdf_off[mat_cdfD[i]]; o.cdfD_len = (int)cdfs[mat_cdfD[i]].size();
         o.widD_off = cdf_wid_off[mat_cdfD[i]];
         o.cdfA_off = cdf_off[mat_cdfA[i]]; o.cdfA_len = (int)cdfs[mat_cdfA[i]].size();
+        o.gD_off = mat_cdfD[i] * (GUIDE_BUCKETS + 1); o.gA_off = mat_cdfA[i] * (GUIDE_BUCKETS + 1);
         o.widA_off = cdf_wid_off[mat_cdfA[i]];
     }
     // aligned acceptors: PhotonObject.py:291-302, MonteCarloFRET.py:124-157
@@ -683,6 +685,19 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     for (auto &c : cdfs)
         for (double v : c) cdfT.push_back(threshold32(v));
     if (cdfT.empty()) cdfT.push_back(0xFFFFFFFFu);
+    // guide tables: thresholds below the first value of every bucket of the top GUIDE_BITS bits
+    std::vector<uint16_t> guide;
+    for (auto &c : cdfs) {
+        std::vector<uint32_t> T;
+        for (double v : c) T.push_back(threshold32(v));
+        for (int b = 0; b <= GUIDE_BUCKETS; b++) {
+            const uint64_t first = (uint64_t)b << (32 - GUIDE_BITS);
+            size_t cnt = 0;
+            while (cnt < T.size() && (uint64_t)T[cnt] < first) cnt++;
+            guide.push_back((uint16_t)(b == GUIDE_BUCKETS ? T.size() : cnt));
+        }
+    }
+    if (guide.empty()) guide.assign(GUIDE_BUCKETS + 1, 0);
 
     auto align = [](size_t v) { return (v + 15) & ~(size_t)15; };
     LdsLayout &lay = img.lay;
@@ -692,6 +707,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.orient = (uint32_t)off; off = align(off + sizeof(DevOrient<real>) * std::max(1, n_mat));
     lay.abs = (uint32_t)off; off = align(off + sizeof(DevAbs<real>) * std::max<size_t>(1, abs.size()));
     lay.cdf = (uint32_t)off; off = align(off + 4 * cdfT.size());
+    lay.guide = (uint32_t)off; off = align(off + 2 * guide.size());
     lay.fx = (uint32_t)off; off = align(off + 4 * energy_fx.size());
     lay.bin = (uint32_t)off; off = align(off + 2 * wid_cbin.size());
     lay.acc = (uint32_t)off;
@@ -707,6 +723,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     if (n_mat) memcpy(img.lds.data() + lay.orient, orient.data(), sizeof(DevOrient<real>) * n_mat);
     if (!abs.empty()) memcpy(img.lds.data() + lay.abs, abs.data(), sizeof(DevAbs<real>) * abs.size());
     memcpy(img.lds.data() + lay.cdf, cdfT.data(), 4 * cdfT.size());
+    memcpy(img.lds.data() + lay.guide, guide.data(), 2 * guide.size());
     memcpy(img.lds.data() + lay.fx, energy_fx.data(), 4 * energy_fx.size());
     memcpy(img.lds.data() + lay.bin, wid_cbin.data(), 2 * wid_cbin.size());
 
@@ -723,7 +740,10 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     o.inv_scale = (real)(1.0 / s.scale_factor);
     o.dir_mode = s.direction_mode; o.wl_mode = s.wavelength_mode; o.start_mat = s.start_material;
     o.wid_fixed = 0;
-    if (src_cdf >= 0) { o.cdf_off = cdf_off[src_cdf]; o.cdf_len = (int)cdfs[src_cdf].size(); }
+    if (src_cdf >= 0) {
+        o.cdf_off = cdf_off[src_cdf]; o.cdf_len = (int)cdfs[src_cdf].size();
+        o.guide_off = src_cdf * (GUIDE_BUCKETS + 1);
+    }
 }
 
 int get_table(const rtmc_scene_desc *d, rtmc_table ref, HostTable &t, const char *what)

@@ -93,7 +93,7 @@ struct DevMat {
     uint32_t pAT[3];   // acceptor pathways
     int32_t cdfD_off, cdfD_len, widD_off;  // donor emission: threshold table, first wavelength id
     int32_t cdfA_off, cdfA_len, widA_off;  // acceptor emission
-    int32_t pad0, pad1;
+    int32_t gD_off, gA_off;                // their guide tables
 };
 
 // Absorption data of one (absorbing medium, wavelength id).
@@ -124,11 +124,12 @@ struct DevSource {
     real inv_scale;  // 1 / ScaleFactor
     int32_t dir_mode, wl_mode, start_mat, wid_fixed;
     int32_t cdf_off, cdf_len;  // source spectrum thresholds; wavelength id = row
+    int32_t guide_off, pad;    // its guide table
 };
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, orient, abs, cdf, fx, bin, acc, hist, total;
+    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, acc, hist, total;
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
@@ -358,6 +359,7 @@ struct Lds {
     const DevOrient<real> *orient;
     const DevAbs<real> *abs;
     const uint32_t *cdf;
+    const uint16_t *guide;  // per threshold table GUIDE_BUCKETS + 1 entries: thresholds below bucket b's first value
     const uint32_t *fx;    // per wavelength id: llrint(wl_source / wl * 2^24) for a single-line source
     const uint16_t *bin;   // per wavelength id: compact detector bin
     unsigned long long *acc;
@@ -368,6 +370,22 @@ struct Lds {
 __device__ __forceinline__ int cdf_pick(const uint32_t *T, int n, uint32_t v)
 {
     int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (T[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo < n ? lo : n - 1;
+}
+
+// The same count found from a guide table: G[b] = number of thresholds below
+// b << (32 - GUIDE_BITS), so the answer lies in [G[b], G[b + 1]] for b = v's top
+// bits and the bisection runs over a handful of entries instead of the table.
+constexpr int GUIDE_BITS = 8;
+constexpr int GUIDE_BUCKETS = 1 << GUIDE_BITS;
+__device__ __forceinline__ int cdf_pick_guided(const uint32_t *T, int n, const uint16_t *G, uint32_t v)
+{
+    const uint32_t b = v >> (32 - GUIDE_BITS);
+    int lo = G[b], hi = G[b + 1];
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
         if (T[mid] <= v) lo = mid + 1; else hi = mid;
@@ -700,7 +718,7 @@ __device__ __forceinline__ void renew_launch(SceneArg<real> sc, const Lds<real> 
     } else {
         p.Dx = s.dir[0]; p.Dy = s.dir[1]; p.Dz = s.dir[2];
     }
-    p.wid = s.wl_mode == 1 ? cdf_pick(lds.cdf + s.cdf_off, s.cdf_len, g.u32(3)) : s.wid_fixed;
+    p.wid = s.wl_mode == 1 ? cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3)) : s.wid_fixed;
     perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
     init_photon_common(sc, p);
 }
