@@ -178,6 +178,55 @@ def aligned_special_values(S):
     return np.array(out + [float(special.erfi(b1)), float(special.erfi(b2))], dtype=np.float64)
 
 
+def _vec(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def element_hit(element, L, D, was_element=False):
+    """FindIntersections of one packed element (raytracer_amd._abi.Element); NaNs for no point."""
+    L_, D_, out = _vec(L), _vec(D), np.zeros(3)
+    fn = lib().orc_element_hit
+    fn.argtypes = [C.POINTER(_abi.Element), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                   C.POINTER(C.c_double)]
+    ok = fn(C.byref(element), _abi.f64_ptr(L_), _abi.f64_ptr(D_), int(bool(was_element)), _abi.f64_ptr(out))
+    return out if ok else np.full(3, np.nan)
+
+
+def cylinder_normal(element, P):
+    P_, out = _vec(P), np.zeros(3)
+    fn = lib().orc_cylinder_normal
+    fn.argtypes = [C.POINTER(_abi.Element), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    fn.restype = None
+    fn(C.byref(element), _abi.f64_ptr(P_), _abi.f64_ptr(out))
+    return out
+
+
+def op_lens(S, n, f, L, D, E):
+    state = _vec(np.concatenate([L, D, E]))
+    fn = lib().orc_op_lens
+    fn.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+    fn.restype = None
+    fn(_abi.f64_ptr(_vec(S)), _abi.f64_ptr(_vec(n)), float(f), _abi.f64_ptr(state))
+    return state
+
+
+def psi(S, nE):
+    fn = lib().orc_psi
+    fn.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    fn.restype = C.c_double
+    special = aligned_special_values(S) if S > 1e-10 else None
+    return float(fn(float(S), _abi.f64_ptr(special) if special is not None else None, _abi.f64_ptr(_vec(nE))))
+
+
+def vect_axis(v):
+    n1, n2 = np.zeros(3), np.zeros(3)
+    fn = lib().orc_vect_axis
+    fn.argtypes = [C.POINTER(C.c_double)] * 3
+    fn.restype = None
+    fn(_abi.f64_ptr(_vec(v)), _abi.f64_ptr(n1), _abi.f64_ptr(n2))
+    return n1, n2
+
+
 def op_interface(S, n, n1, n2, L, D, E):
     """(tir, R, sgn), refracted(L,D,E), reflected(L,D,E) for one incidence."""
     state = np.ascontiguousarray(np.concatenate([L, D, E]), dtype=np.float64)

@@ -1312,6 +1312,42 @@ ORC_EXPORT int orc_step_tape(const orc_scene *s, uint32_t n, rtmc_photon_soa *b,
     return RTMC_OK;
 }
 
+/* single operations for the known-answer vectors */
+ORC_EXPORT int orc_element_hit(const rtmc_element *e, const double *L, const double *D, int was_element, double *out)
+{
+    return element_intersect(e, L, D, was_element, out);
+}
+ORC_EXPORT void orc_cylinder_normal(const rtmc_element *e, const double *P, double *n)
+{
+    double S[3];
+    cylinder_plane(e, P, S, n);
+}
+/* Lens.ExecuteOperation on a photon state (L, D, E) with plane (S, n) */
+ORC_EXPORT void orc_op_lens(const double *S, const double *n, double f, double *state)
+{
+    ph_t p;
+    memset(&p, 0, sizeof p);
+    memcpy(p.L, state, 24); memcpy(p.D, state + 3, 24); memcpy(p.E, state + 6, 24);
+    memcpy(p.op_S, S, 24); memcpy(p.op_n, n, 24);
+    prepare_execution(&p);
+    focus_thin_lens(&p, f);
+    post_process(&p);
+    memcpy(state, p.L, 24); memcpy(state + 3, p.D, 24); memcpy(state + 6, p.E, 24);
+}
+ORC_EXPORT double orc_psi(double S, const double *special, const double *nE)
+{
+    omat_t M;
+    memset(&M, 0, sizeof M);
+    M.m.align_S = S;
+    if (special) {
+        M.erf_m1 = special[0] + special[1] * I; M.erf_p1 = special[2] + special[3] * I;
+        M.erf_m2 = special[4] + special[5] * I; M.erf_p2 = special[6] + special[7] * I;
+        M.erfi_1 = special[8]; M.erfi_2 = special[9];
+    }
+    return lambert_beer_full_integral(&M, nE);
+}
+ORC_EXPORT void orc_vect_axis(const double *v, double *n1, double *n2) { vect_axis(v, n1, n2); }
+
 /* same contract as rtmc_op_intersect */
 ORC_EXPORT int orc_op_intersect(const orc_scene *s, uint32_t n, const double *loc, const double *dir, double *out)
 {

@@ -20,7 +20,7 @@ Harness-side shims (none touches the physics):
     `choice(a, p=p)` = one `random_sample()` + `searchsorted(cdf, u, 'right')`),
     so a wrapped run and an unwrapped run with the same seed are identical.
 
-usage:  python tests/golden/make_golden.py traces|tallies|materials|kat|all
+usage:  python tests/golden/make_golden.py traces|tallies|materials|kat|kat_shapes|all
 """
 from __future__ import annotations
 
@@ -475,6 +475,126 @@ def gen_kat(ref):
     print("kat:", sorted(out))
 
 
+def gen_kat_shapes(ref):
+    """Single-operation vectors of the reference for the shapes other than the
+    rectangle, the thin lens and the aligned-dye orientation integral."""
+    geo, pho, rtu = ref.mod["Geometries"], ref.mod["PhotonObject"], ref.mod["RTUtils"]
+    rng = np.random.RandomState(11)
+    out = {}
+
+    class P:
+        pass
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    def as_point(x):
+        return np.asarray(x, dtype=float)
+
+    ph = P()
+    n = 300
+    # circles: rays aimed at a disc of twice the radius around the centre
+    S = rng.uniform(-2, 2, (n, 3)); N = rng.normal(size=(n, 3)); R = rng.uniform(0.2, 1.5, n)
+    L = rng.uniform(-3, 3, (n, 3))
+    D = np.zeros((n, 3)); hit = np.zeros((n, 3)); nn = np.zeros((n, 3))
+    for i in range(n):
+        c = geo.Circle(R[i], S[i].copy(), N[i].copy(), ph)
+        nn[i] = c.DirectionVector
+        a = unit(np.cross(nn[i], [0.3, 0.5, 0.8]))
+        target = S[i] + 2 * R[i] * rng.uniform(-1, 1) * a + 2 * R[i] * rng.uniform(-1, 1) * np.cross(nn[i], a)
+        D[i] = (target - L[i]) * rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
+        ph.Location, ph.Direction = L[i].copy(), D[i].copy()
+        hit[i] = as_point(c.FindIntersections())
+    out.update(circ_S=S, circ_N=N, circ_n=nn, circ_R=R, circ_L=L, circ_D=D, circ_hit=hit)
+
+    # triangles
+    T = rng.uniform(-2, 2, (n, 3, 3)); L = rng.uniform(-3, 3, (n, 3))
+    D = np.zeros((n, 3)); hit = np.zeros((n, 3)); sup = np.zeros((n, 3)); nrm = np.zeros((n, 3))
+    for i in range(n):
+        t = geo.Triangle(T[i, 0].copy(), T[i, 1].copy(), T[i, 2].copy(), ph)
+        sup[i], nrm[i] = t.SupportVector, t.DirectionVector
+        w = rng.uniform(-0.4, 1.2, 3); w /= w.sum()
+        target = w[0] * T[i, 0] + w[1] * T[i, 1] + w[2] * T[i, 2]
+        D[i] = (target - L[i]) * rng.uniform(0.5, 2.0)
+        ph.Location, ph.Direction = L[i].copy(), D[i].copy()
+        hit[i] = as_point(t.FindIntersections())
+    out.update(tri_T=T, tri_L=L, tri_D=D, tri_hit=hit, tri_S=sup, tri_n=nrm)
+
+    # cylinders: fresh photons, photons coming from an element, and photons that sit on the wall
+    P1 = rng.uniform(-2, 2, (n, 3)); P2 = P1 + rng.normal(size=(n, 3)) * rng.uniform(0.5, 2.0, (n, 1))
+    R = rng.uniform(0.2, 1.0, n)
+    L = rng.uniform(-3, 3, (n, 3)); D = np.zeros((n, 3)); was = rng.rand(n) < 0.5
+    hit = np.zeros((n, 3)); normal = np.full((n, 3), np.nan)
+    for i in range(n):
+        c = geo.Cylinder(R[i], P1[i].copy(), P2[i].copy(), ph)
+        axis = unit(P2[i] - P1[i])
+        a = unit(np.cross(axis, [0.3, 0.5, 0.8]))
+        target = P1[i] + rng.uniform(-0.2, 1.2) * (P2[i] - P1[i]) + 1.5 * R[i] * rng.uniform(-1, 1) * a
+        if i % 5 == 4:  # start on the wall: move the start to a wall point of some line first
+            ph.Location, ph.Direction, ph.WasElement = L[i].copy(), (target - L[i]), False
+            q = as_point(c.FindIntersections())
+            if not np.isnan(q).any():
+                L[i] = q
+        D[i] = (target - L[i]) * rng.choice([-1.0, 1.0]) * rng.uniform(0.5, 2.0)
+        if not np.any(D[i]):
+            D[i] = rng.normal(size=3)
+        ph.Location, ph.Direction, ph.WasElement = L[i].copy(), D[i].copy(), bool(was[i])
+        try:
+            hit[i] = as_point(c.FindIntersections())
+        except UnboundLocalError:      # both line points within 1e-7 of the photon: the reference fails
+            hit[i] = np.nan
+        if not np.isnan(hit[i]).any():
+            ph.PointCy = hit[i].copy()
+            normal[i] = as_point(c.FindNormalCylinder())
+    out.update(cyl_P1=P1, cyl_P2=P2, cyl_R=R, cyl_L=L, cyl_D=D, cyl_was=was, cyl_hit=hit,
+               cyl_normal=normal)
+
+    # thin lens
+    m = 200
+    S = rng.uniform(-1, 1, (m, 3)); N = rng.normal(size=(m, 3)); N /= np.linalg.norm(N, axis=1)[:, None]
+    L = rng.uniform(-2, 2, (m, 3)); D = rng.normal(size=(m, 3)); D /= np.linalg.norm(D, axis=1)[:, None]
+    E = np.cross(D, rng.normal(size=(m, 3))); E /= np.linalg.norm(E, axis=1)[:, None]
+    f = rng.uniform(0.2, 2.0, m) * rng.choice([-1.0, 1.0], m)
+    res = np.zeros((m, 9))
+    with contextlib.redirect_stdout(io.StringIO()):
+        air = ref.mod["Materials"].MaterialObj("kat_air", 1.0)
+    for i in range(m):
+        p = pho.Photon(StartingMaterial=air)
+        p.Location, p.Direction = L[i].copy(), D[i].copy()
+        p.ElectricFieldVector = E[i].copy()
+        p.OperationPlane = [S[i].copy(), N[i].copy()]
+        p.PrepareExecution()
+        p.FocusThinLens(f[i])
+        p.PostProcessExecution()
+        res[i] = np.concatenate([p.Location, p.Direction, p.ElectricFieldVector])
+    out.update(lens_S=S, lens_n=N, lens_L=L, lens_D=D, lens_E=E, lens_f=f, lens_res=res)
+
+    # orientation integral of aligned dyes
+    Ss = np.array([1e-99, 0.02, 0.05, 0.1, 0.3, 0.785, 1.5, 3.0])
+    nE = rng.normal(size=(40, 3)); nE /= np.linalg.norm(nE, axis=1)[:, None]
+    nE[0] = [0, 0, 1.0]; nE[1] = [1.0, 0, 0]; nE[2] = [0, 1e-6, 1.0]; nE[2] /= np.linalg.norm(nE[2])
+    psi = np.zeros((len(Ss), len(nE)))
+
+    class M:
+        pass
+    p = pho.Photon(StartingMaterial=air)
+    p.CurrentMaterial = M()
+    with contextlib.redirect_stdout(io.StringIO()):
+        for a, sv in enumerate(Ss):
+            p.CurrentMaterial.AlignS = sv
+            for b in range(len(nE)):
+                psi[a, b] = p.LambertBeerFullIntegral(nE[b].copy())
+    out.update(psi_S=Ss, psi_nE=nE, psi=psi)
+
+    # MakeVectAxis
+    V = rng.normal(size=(20, 3)); V /= np.linalg.norm(V, axis=1)[:, None]
+    V[0] = [1.0, 0, 0]; V[1] = [0, 1.0, 0]; V[2] = [0, 0, 1.0]
+    out.update(mva_v=V, mva_tm=np.array([rtu.MakeVectAxis(v.copy()) for v in V]))
+    np.savez_compressed(os.path.join(HERE, "kat_shapes.npz"), **out)
+    print("kat_shapes:", {k: v.shape for k, v in out.items()})
+    print("cylinder hits", int((~np.isnan(hit[:, 0])).sum()), "of", n)
+
+
 def _tally_worker(args):
     name, seed, n = args
     ref = Reference()
@@ -551,6 +671,8 @@ def main():
     try:
         if what in ("kat", "all"):
             gen_kat(ref)
+        if what in ("kat_shapes", "all"):
+            gen_kat_shapes(ref)
         if what in ("materials", "all"):
             gen_materials(ref)
         if what in ("traces", "all"):

@@ -150,6 +150,38 @@ def test_rectangle_known_answers_on_gpu(golden_dir):
             assert np.allclose(got, ref, rtol=1e-12, atol=1e-12)
 
 
+def test_shape_known_answers_on_gpu(golden_dir):
+    """Circle / Triangle / Cylinder FindIntersections of the reference
+    (tests/golden/kat_shapes.npz; fresh photons, i.e. the forward rule of the
+    cylinder) through rtmc_op_intersect, float64 and float32."""
+    from raytracer_amd import Geometries
+    from raytracer_amd.scene import intersect_single
+    k = np.load(golden_dir + "/kat_shapes.npz")
+    cases = []
+    for i in range(0, 300, 3):
+        cases.append((Geometries.Circle(k["circ_R"][i], k["circ_S"][i], k["circ_N"][i]),
+                      k["circ_L"][i], k["circ_D"][i], k["circ_hit"][i]))
+        cases.append((Geometries.Triangle(*k["tri_T"][i]), k["tri_L"][i], k["tri_D"][i], k["tri_hit"][i]))
+    for i in range(300):
+        if not k["cyl_was"][i] and i % 5 != 4:
+            cases.append((Geometries.Cylinder(k["cyl_R"][i], k["cyl_P1"][i], k["cyl_P2"][i]),
+                          k["cyl_L"][i], k["cyl_D"][i], k["cyl_hit"][i]))
+    assert len(cases) > 300
+    edge = 0
+    for g, L, D, ref in cases:
+        got = intersect_single(g, L, D)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), (g.kind, got, ref)
+        if not np.isnan(ref).any():
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-9), (g.kind, got, ref)
+        got32 = intersect_single(g, L, D, precision=_abi.F32)
+        if np.isnan(got32).any() != np.isnan(ref).any():
+            edge += 1          # a ray within float32 rounding of the rim
+        elif not np.isnan(ref).any():
+            far = max(1.0, float(np.linalg.norm(ref - L)))
+            assert np.allclose(got32, ref, atol=2e-5 * far), (g.kind, got32, ref)
+    assert edge <= 3, edge
+
+
 def _sigma(n, p):
     return max(1.0, (n * p * (1 - p)) ** 0.5)
 

@@ -134,3 +134,66 @@ def test_event_layout_samplers_follow_the_reference_laws(oracle_mod, name, n):
     p_cap = 0.5 * (a["n_capped"] + b["n_capped"]) / n
     sd = ((3 * ma) ** 2 + p_cap * 1.0e8) ** 0.5
     assert abs(ma - mb) <= 5 * sd * (2.0 / n) ** 0.5
+
+
+def _packed(geometry):
+    from raytracer_amd import Elements, OpticalObject
+    from raytracer_amd import scene as sc
+    oe = OpticalObject.OpticalObject(Elements.Mirror(None), geometry)
+    return sc.pack_element(oe, [], None, [])
+
+
+def _same_points(got, ref, tol):
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), (got, ref)
+    if not np.isnan(ref).any():
+        assert np.allclose(got, ref, rtol=tol, atol=tol), (got, ref)
+
+
+def test_shape_known_answers(oracle_mod, golden_dir):
+    """Circle / Triangle / Cylinder FindIntersections, the cylinder's tangent
+    normal, the thin lens, the orientation integral and MakeVectAxis against
+    single calls of the reference (tests/golden/kat_shapes.npz)."""
+    from raytracer_amd import Geometries
+    k = np.load(golden_dir + "/kat_shapes.npz")
+    for i in range(len(k["circ_R"])):
+        g = Geometries.Circle(k["circ_R"][i], k["circ_S"][i], k["circ_N"][i])
+        assert np.allclose(g.DirectionVector, k["circ_n"][i], atol=1e-15)
+        _same_points(oracle_mod.element_hit(_packed(g), k["circ_L"][i], k["circ_D"][i]), k["circ_hit"][i], 1e-12)
+    n_hit = 0
+    for i in range(len(k["tri_T"])):
+        g = Geometries.Triangle(*k["tri_T"][i])
+        assert np.allclose(g.SupportVector, k["tri_S"][i], atol=1e-15)
+        assert np.allclose(g.DirectionVector, k["tri_n"][i], atol=1e-15)
+        _same_points(oracle_mod.element_hit(_packed(g), k["tri_L"][i], k["tri_D"][i]), k["tri_hit"][i], 1e-12)
+        n_hit += not np.isnan(k["tri_hit"][i]).any()
+    assert 50 < n_hit < 250
+    for i in range(len(k["cyl_R"])):
+        g = Geometries.Cylinder(k["cyl_R"][i], k["cyl_P1"][i], k["cyl_P2"][i])
+        e = _packed(g)
+        got = oracle_mod.element_hit(e, k["cyl_L"][i], k["cyl_D"][i], bool(k["cyl_was"][i]))
+        ref = k["cyl_hit"][i].copy()
+        # a photon on the wall: whether its own position (a line parameter of 1e-16 of either
+        # sign) counts as "behind" is decided by rounding; the search discards that point
+        # anyway (RayTrace.py:134), so it is the same answer as no point
+        for pt in (got, ref):
+            if not np.isnan(pt).any() and np.linalg.norm(pt - k["cyl_L"][i]) < 1e-8:
+                pt[:] = np.nan
+        _same_points(got, ref, 1e-10)
+        if not np.isnan(k["cyl_hit"][i]).any() and np.linalg.norm(k["cyl_hit"][i] - k["cyl_L"][i]) > 1e-8:
+            assert np.allclose(oracle_mod.cylinder_normal(e, k["cyl_hit"][i]), k["cyl_normal"][i], atol=1e-12)
+    for i in range(len(k["lens_f"])):
+        got = oracle_mod.op_lens(k["lens_S"][i], k["lens_n"][i], k["lens_f"][i], k["lens_L"][i],
+                                 k["lens_D"][i], k["lens_E"][i])
+        assert np.allclose(got, k["lens_res"][i], rtol=1e-11, atol=1e-12), i
+    from raytracer_amd.scene import orientation_integral_constants
+    for a, S in enumerate(k["psi_S"]):
+        P, Q = orientation_integral_constants(float(S))
+        for b, nE in enumerate(k["psi_nE"]):
+            ref = k["psi"][a, b]
+            assert oracle_mod.psi(float(S), nE) == pytest.approx(ref, rel=1e-12, abs=1e-15)
+            mine = abs(P * (nE[0] ** 2 + nE[1] ** 2) + Q * nE[2] ** 2)   # what the kernels evaluate
+            mine = 0.0 if mine < 1e-10 else mine
+            assert mine == pytest.approx(ref, rel=1e-9, abs=1e-13), (S, nE)
+    for v, tm in zip(k["mva_v"], k["mva_tm"]):
+        n1, n2 = oracle_mod.vect_axis(v)
+        assert np.allclose(n1, tm[:, 1], atol=1e-15) and np.allclose(n2, tm[:, 2], atol=1e-15)
