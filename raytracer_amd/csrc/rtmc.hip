@@ -138,8 +138,12 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     for (;;) {
         // The renew block costs about half a loop iteration whatever the number of
         // lanes in it; it waits until enough lanes want it (or nobody can step).
+        // (Single exit and no `continue`: with two back edges the compiler copied the
+        // whole photon record to other registers and back on every iteration.)
         const unsigned long long want = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
-        if (want != 0ull && (__popcll(want) >= RENEW_THRESHOLD || __ballot(need == NEED_NONE) == 0ull)) {
+        const unsigned long long stepping = __ballot(need == NEED_NONE);
+        if ((want | stepping) == 0ull) break;  // every lane is switched off
+        if (want != 0ull && (__popcll(want) >= RENEW_THRESHOLD || stepping == 0ull)) {
             SECTION_BEGIN();
 #ifdef RTMC_PROFILE_SECTIONS
             const unsigned long long renew_mask = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
@@ -212,10 +216,6 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 need = NEED_NONE;
             }
             SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);
-        }
-        if (__ballot(need == NEED_NONE) == 0ull) {
-            if (__ballot(need != NEED_OFF) == 0ull) break;
-            continue;
         }
         SECTION_BEGIN();
 #ifdef RTMC_PROFILE_SECTIONS
