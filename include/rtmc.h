@@ -280,6 +280,18 @@ int rtmc_step_tape(rtmc_scene *scene, int device, int precision, uint32_t n,
 int rtmc_op_intersect(rtmc_scene *scene, int device, int precision, uint32_t n,
                       const double *loc, const double *dir, double *out_points);
 
+/* RayTrace.CheckElementsForCrossingPoint (RayTrace.py:120-154) for `n`
+ * photon states: the nearest element whose point the photon may go to next.
+ * Read from `photons`: loc, dir, old_point, last_element, was_element,
+ * reflected (Cylinder.FindIntersections depends on was_element,
+ * Geometries.py:102-107).  element[k] is the index of the element found or -1
+ * (the reference then keeps its previous FirstEl), distance[k] its
+ * SmallestDistance (+inf if none), points[3k..] Photon.PointCy ((0,0,0) if
+ * none). */
+int rtmc_op_crossing(rtmc_scene *scene, int device, int precision, uint32_t n,
+                     const rtmc_photon_soa *photons, int32_t *element, double *distance,
+                     double *points);
+
 /* Number of wavelengths a photon can carry in this scene (source lines or
  * table rows plus every emission-table row) and their values. */
 int rtmc_scene_wavelengths(const rtmc_scene *scene, int64_t *count, double *values,

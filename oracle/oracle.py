@@ -144,6 +144,19 @@ class OracleScene:
                                    _abi.f64_ptr(tr.reshape(-1)) if trace else None))
         return tr
 
+    def crossing(self, batch):
+        n = batch["wavelength"].shape[0]
+        el = np.full(n, -1, dtype=np.int32)
+        dist = np.zeros(n)
+        pts = np.zeros((n, 3))
+        s = _scene.batch_struct(batch)
+        fn = lib().orc_op_crossing
+        fn.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_abi.PhotonSoA), C.POINTER(C.c_int32),
+                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _check(fn(self.handle, n, C.byref(s), _abi.i32_ptr(el), _abi.f64_ptr(dist),
+                  _abi.f64_ptr(pts.reshape(-1))))
+        return el, dist, pts
+
     def intersect(self, loc, direction):
         loc = np.ascontiguousarray(loc, dtype=np.float64).reshape(-1, 3)
         direction = np.ascontiguousarray(direction, dtype=np.float64).reshape(-1, 3)

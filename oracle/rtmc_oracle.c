@@ -1348,6 +1348,22 @@ ORC_EXPORT double orc_psi(double S, const double *special, const double *nE)
 }
 ORC_EXPORT void orc_vect_axis(const double *v, double *n1, double *n2) { vect_axis(v, n1, n2); }
 
+/* same contract as rtmc_op_crossing */
+ORC_EXPORT int orc_op_crossing(const orc_scene *s, uint32_t n, const rtmc_photon_soa *b, int32_t *element,
+                               double *distance, double *points)
+{
+    for (uint32_t k = 0; k < n; k++) {
+        ph_t p;
+        soa_load(b, k, &p, s);
+        if (p.old_el < 0) p.was_element = 0; /* nothing visited yet */
+        find_crossing(s, &p);
+        element[k] = isfinite(p.smallest) ? p.first_el : -1;
+        distance[k] = p.smallest;
+        memcpy(points + 3 * k, p.point_cy, 3 * sizeof(double));
+    }
+    return RTMC_OK;
+}
+
 /* same contract as rtmc_op_intersect */
 ORC_EXPORT int orc_op_intersect(const orc_scene *s, uint32_t n, const double *loc, const double *dir, double *out)
 {

@@ -142,6 +142,32 @@ class RayTrace:
             self.IOOperator.SaveLog()
         return t
 
+    def CheckElementsForCrossingPoint(self):
+        """Nearest valid element on the current trajectory of `self.Photon`
+        (reference RayTrace.py:120-154): sets `SmallestDistance`, `FirstEl`,
+        `el_n`, `Photon.PointCy` and `OldElement` like the reference does.
+        The search itself runs on the device (`rtmc_op_crossing`)."""
+        ph = self.Photon
+        batch = _scene.new_photon_batch(1)
+        old_point = getattr(self, "OldPoint", ph.Location)
+        for j in range(3):
+            batch["loc"][j, 0] = ph.Location[j]
+            batch["dir"][j, 0] = ph.Direction[j]
+            batch["old_point"][j, 0] = old_point[j]
+        last = getattr(self, "OldElement", None)
+        batch["last_element"][0] = self.OpticalElements.index(last) if last is not None else -1
+        batch["was_element"][0] = int(bool(ph.WasElement)) if last is not None else 0
+        batch["reflected"][0] = int(bool(ph.Reflected))
+        device = self.Device if self.Device is not None else distributed.local_device()
+        el, dist, pts = self.Scene().crossing(batch, device=device, precision=_abi.F64)
+        self.SmallestDistance = float(dist[0])
+        ph.PointCy = [0, 0, 0] if el[0] < 0 else pts[0].copy()
+        if el[0] >= 0:
+            self.FirstEl = self.OpticalElements[int(el[0])]
+            self.el_n = int(el[0])
+        self.OldElement = getattr(self, "FirstEl", None)
+        return self.OldElement
+
     def _publish(self, t):
         """Copy the tallies onto the element objects the way the reference
         leaves them after a run (Elements.py:15,39,139-144)."""

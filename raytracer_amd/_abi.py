@@ -27,7 +27,7 @@ STATUS = ["Start", "Absorbed", "ReemittedDonor", "ReemittedAcceptor", "InternalC
 
 EXPORTS = ["rtmc_version", "rtmc_last_error", "rtmc_scene_create", "rtmc_scene_destroy",
            "rtmc_run", "rtmc_last_kernel_ms", "rtmc_step_tape", "rtmc_op_intersect",
-           "rtmc_scene_wavelengths"]
+           "rtmc_scene_wavelengths", "rtmc_op_crossing"]
 
 c_double3 = C.c_double * 3
 c_double9 = C.c_double * 9
@@ -127,6 +127,9 @@ def bind(lib):
     lib.rtmc_op_intersect.restype = C.c_int
     lib.rtmc_op_intersect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, _f64p, _f64p,
                                       _f64p]
+    lib.rtmc_op_crossing.restype = C.c_int
+    lib.rtmc_op_crossing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(PhotonSoA),
+                                     _i32p, _f64p, _f64p]
     lib.rtmc_scene_wavelengths.restype = C.c_int
     lib.rtmc_scene_wavelengths.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _f64p, C.c_int64]
     return lib

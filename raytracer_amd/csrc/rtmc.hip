@@ -272,7 +272,8 @@ struct SoaDev {
 template <typename real>
 __global__ void __launch_bounds__(TRACE_BLOCK)
 step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_steps, int launch,
-                 const double *tape, const unsigned long long *tape_off, double *trace, int *overrun)
+                 const double *tape, const unsigned long long *tape_off, double *trace, int *overrun,
+                 int32_t *cross_el, double *cross_dist, double *cross_pts)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     SceneArg<real> sc = scene_ref(scene);
@@ -314,6 +315,17 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
                        (double)nz * b.old_point[2][k] - d0;
             set_admissibility(p, le.type & 0xFF, (s > 0) - (s < 0), nx * p.Dx + ny * p.Dy + nz * p.Dz);
         }
+    }
+    if (cross_el) {  // rtmc_op_crossing: the search only
+        real dnorm;
+        const Nearest<real> nr = nearest_valid_hit<FEAT_ALIGNED | FEAT_SHAPES>(hot, p, dnorm);
+        const bool none = nr.e < 0;
+        cross_el[k] = nr.e;
+        cross_dist[k] = none ? __builtin_huge_val() : (double)(M<real>::abs(nr.t) * dnorm);
+        cross_pts[3 * k] = none ? 0.0 : (double)(p.Lx + nr.t * p.Dx);
+        cross_pts[3 * k + 1] = none ? 0.0 : (double)(p.Ly + nr.t * p.Dy);
+        cross_pts[3 * k + 2] = none ? 0.0 : (double)(p.Lz + nr.t * p.Dz);
+        return;
     }
     NoTally tally;
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
@@ -1167,10 +1179,33 @@ struct DeviceBuffer {
 };
 }  // namespace
 
+static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
+                          const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
+                          double *trace, int32_t *cross_el, double *cross_dist, double *cross_pts);
+
 RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
                               const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
                               double *trace)
 {
+    return step_tape_impl(s, device, precision, n, b, tape, tape_off, n_steps, launch, trace, nullptr, nullptr, nullptr);
+}
+
+RTMC_API int rtmc_op_crossing(rtmc_scene *s, int device, int precision, uint32_t n, const rtmc_photon_soa *b,
+                                int32_t *element, double *distance, double *points)
+{
+    if (!element || !distance || !points) return fail(RTMC_EINVAL, "null argument");
+    if (n == 0) return RTMC_OK;
+    const double no_tape = 0.0;
+    std::vector<uint64_t> off(n + 1, 0);
+    return step_tape_impl(s, device, precision, n, const_cast<rtmc_photon_soa *>(b), &no_tape, off.data(), 0, 0,
+                          nullptr, element, distance, points);
+}
+
+static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
+                          const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
+                          double *trace, int32_t *cross_el, double *cross_dist, double *cross_pts)
+{
+    const bool crossing = cross_el != nullptr;
     if (!s || !b || !tape || !tape_off) return fail(RTMC_EINVAL, "null argument");
     if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
     if (n == 0) return RTMC_OK;
@@ -1192,19 +1227,26 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
         std::map<double, int32_t> ids;
         for (size_t w = s->wl.size(); w-- > 0;) ids[s->wl[w]] = (int32_t)w;
         for (uint32_t k = 0; k < n; k++) {
-            auto a = ids.find(b->wavelength[k]), c = ids.find(b->start_wavelength[k]);
-            if (a == ids.end() || c == ids.end())
-                return fail(RTMC_EINVAL, "photon %u carries a wavelength that is neither a source line nor an emission-table row", k);
-            wid[k] = a->second; wid0[k] = c->second;
+            if (!crossing) {  // the search does not look at wavelengths
+                auto a = ids.find(b->wavelength[k]), c = ids.find(b->start_wavelength[k]);
+                if (a == ids.end() || c == ids.end())
+                    return fail(RTMC_EINVAL, "photon %u carries a wavelength that is neither a source line nor an emission-table row", k);
+                wid[k] = a->second; wid0[k] = c->second;
+            }
             if (b->material[k] < 0 || b->material[k] >= s->n_mat) return fail(RTMC_EINVAL, "photon %u: material out of range", k);
             if (b->last_element[k] < -1 || b->last_element[k] >= s->n_el) return fail(RTMC_EINVAL, "photon %u: element out of range", k);
             uint64_t seg = tape_off[k + 1] - tape_off[k];
-            if (b->tape_pos[k] < 0 || (uint64_t)b->tape_pos[k] > seg) return fail(RTMC_EINVAL, "photon %u: tape position outside its segment", k);
+            if (!crossing && (b->tape_pos[k] < 0 || (uint64_t)b->tape_pos[k] > seg)) return fail(RTMC_EINVAL, "photon %u: tape position outside its segment", k);
         }
     }
     const size_t nd = 15, ni = 9;  // double / int32 columns
     const size_t tape_len = tape_off[n];
-    DeviceBuffer dbuf, ibuf, tbuf, obuf, trbuf, ovbuf;
+    DeviceBuffer dbuf, ibuf, tbuf, obuf, trbuf, ovbuf, cebuf, cdbuf, cpbuf;
+    if (crossing) {
+        HIP_TRY(hipMalloc(&cebuf.ptr, 4 * (size_t)n));
+        HIP_TRY(hipMalloc(&cdbuf.ptr, 8 * (size_t)n));
+        HIP_TRY(hipMalloc(&cpbuf.ptr, 24 * (size_t)n));
+    }
     HIP_TRY(hipMalloc(&dbuf.ptr, 8 * nd * n));
     HIP_TRY(hipMalloc(&ibuf.ptr, 4 * ni * n));
     HIP_TRY(hipMalloc(&tbuf.ptr, 8 * std::max<size_t>(tape_len, 1)));
@@ -1243,12 +1285,21 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
     if (f32)
         hipLaunchKernelGGL(step_tape_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
                            (const DevScene<float> *)p.scene32, sd, n, n_steps, launch, (const double *)tbuf.ptr,
-                           (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr);
+                           (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr,
+                           (int32_t *)cebuf.ptr, (double *)cdbuf.ptr, (double *)cpbuf.ptr);
     else
         hipLaunchKernelGGL(step_tape_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
                            (const DevScene<double> *)p.scene64, sd, n, n_steps, launch, (const double *)tbuf.ptr,
-                           (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr);
+                           (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr,
+                           (int32_t *)cebuf.ptr, (double *)cdbuf.ptr, (double *)cpbuf.ptr);
     HIP_TRY(hipGetLastError());
+    if (crossing) {  // the batch itself is left as it was
+        HIP_TRY(hipMemcpyAsync(cross_el, cebuf.ptr, 4 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
+        HIP_TRY(hipMemcpyAsync(cross_dist, cdbuf.ptr, 8 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
+        HIP_TRY(hipMemcpyAsync(cross_pts, cpbuf.ptr, 24 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
+        HIP_TRY(hipStreamSynchronize(p.stream));
+        return RTMC_OK;
+    }
     // results
     double *hdst[nd];
     for (int j = 0; j < 3; j++) { hdst[j] = b->loc[j]; hdst[3 + j] = b->dir[j]; hdst[6 + j] = b->efield[j]; hdst[9 + j] = b->old_point[j]; }

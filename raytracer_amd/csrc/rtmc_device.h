@@ -181,6 +181,10 @@ struct HotScene {
     real inv_scale;
 };
 
+// Code a scene may need beyond rectangles with isotropic dyes; kernels are
+// instantiated per combination so that the common case carries none of it.
+enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2 };
+
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
 // arithmetic helpers
@@ -954,6 +958,53 @@ __device__ __forceinline__ void scan_axis_group(const HitChunk<real> *chunks, in
     }
 }
 
+// RayTrace.py:120-154 CheckElementsForCrossingPoint: the nearest element whose
+// point the photon may go to next.  Candidates are ordered by |t| (the line
+// parameter); the distance is |t| |D|.  Admissibility: see set_admissibility.
+// The element the photon sits on is skipped by index; the reference rejects it
+// through its 1e-8 distance test (RayTrace.py:134), which the float64
+// instantiation keeps.  `dnorm` returns |D|.
+template <int FEATURES, typename real>
+__device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> &sc, const Photon<real> &p, real &dnorm)
+{
+    constexpr bool SHAPES = (FEATURES & FEAT_SHAPES) != 0;
+    const real inv_x = M<real>::rcp(p.Dx), inv_y = M<real>::rcp(p.Dy), inv_z = M<real>::rcp(p.Dz);
+    const real m_x = -p.Lx * inv_x, m_y = -p.Ly * inv_y, m_z = -p.Lz * inv_z;
+    dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+    const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
+    const bool adm_all = (p.flags & F_ADM_ALL) != 0u;
+    Nearest<real> nearest;
+    nearest.t = M<real>::inf();
+    nearest.e = -1;
+    const HitChunk<real> *chunks = sc.hits;
+    scan_axis_group(chunks, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm, nearest);
+    chunks += sc.n_group[0];
+    scan_axis_group(chunks, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm, nearest);
+    chunks += sc.n_group[1];
+    scan_axis_group(chunks, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm, nearest);
+    chunks += sc.n_group[2];
+    for (int c = 0; c < sc.n_group[3]; c++) {
+        const HitChunk<real> ch = load_uniform(chunks + c);
+#pragma unroll
+        for (int k = 0; k < HIT_CHUNK; k++) {
+            const int index = ch.r[k].index;
+            if (index < 0) continue;  // padding
+            real t;
+            if (SHAPES) {
+                const DevElem<real> e = load_uniform(sc.elems + index);
+                const bool wall = (e.type >> 8) == RTMC_GEOM_CYLINDER;  // may be met again right away
+                const bool inside = shape_hit(e, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, (p.flags & F_WAS_EL) != 0u,
+                                              index == skip, dnorm, t);
+                consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm);
+            } else {
+                const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
+                consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
+            }
+        }
+    }
+    return nearest;
+}
+
 // Tally sinks -----------------------------------------------------------------
 // LdsTally: the trace kernel (workgroup accumulators in LDS, detector
 // histogram in HBM).  NoTally: the step-wise kernel.
@@ -998,9 +1049,6 @@ struct NoTally {
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 
-// Code a scene may need beyond rectangles with isotropic dyes; kernels are
-// instantiated per combination so that the common case carries none of it.
-enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2 };
 
 // One iteration of the loop body, RayTrace.py:178-195, up to the point where an
 // absorbed photon needs its pathway drawn: the caller does that
@@ -1015,47 +1063,8 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     // the variates of this iteration (every lane computes its block together;
     // which words are used depends on what the iteration turns out to be)
     g.block((uint32_t)p.iter, BLK_STEP);
-    // ---- RayTrace.py:120-154 CheckElementsForCrossingPoint -----------------
-    // Candidates are ordered by |t| (the line parameter); the distance is
-    // |t| |D|.  Admissibility: see set_admissibility.  The element the photon
-    // sits on is skipped by index; the reference rejects it through its 1e-8
-    // distance test (RayTrace.py:134), which the float64 instantiation keeps.
-    const real inv_x = M<real>::rcp(p.Dx), inv_y = M<real>::rcp(p.Dy), inv_z = M<real>::rcp(p.Dz);
-    const real m_x = -p.Lx * inv_x, m_y = -p.Ly * inv_y, m_z = -p.Lz * inv_z;
-    const real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
-    const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
-    const bool adm_all = (p.flags & F_ADM_ALL) != 0u;
-    Nearest<real> nearest;
-    nearest.t = M<real>::inf();
-    nearest.e = -1;
-    {
-        const HitChunk<real> *chunks = sc.hits;
-        scan_axis_group(chunks, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm, nearest);
-        chunks += sc.n_group[0];
-        scan_axis_group(chunks, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm, nearest);
-        chunks += sc.n_group[1];
-        scan_axis_group(chunks, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm, nearest);
-        chunks += sc.n_group[2];
-        for (int c = 0; c < sc.n_group[3]; c++) {
-            const HitChunk<real> ch = load_uniform(chunks + c);
-#pragma unroll
-            for (int k = 0; k < HIT_CHUNK; k++) {
-                const int index = ch.r[k].index;
-                if (index < 0) continue;  // padding
-                real t;
-                if (SHAPES) {
-                    const DevElem<real> e = load_uniform(sc.elems + index);
-                    const bool wall = (e.type >> 8) == RTMC_GEOM_CYLINDER;  // may be met again right away
-                    const bool inside = shape_hit(e, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, (p.flags & F_WAS_EL) != 0u,
-                                                  index == skip, dnorm, t);
-                    consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm);
-                } else {
-                    const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
-                    consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
-                }
-            }
-        }
-    }
+    real dnorm;
+    const Nearest<real> nearest = nearest_valid_hit<FEATURES>(sc, p, dnorm);
     const real best_t = nearest.t;
     const int best_e = nearest.e;
     const bool stale = best_e < 0;

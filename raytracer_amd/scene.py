@@ -323,6 +323,19 @@ class Scene:
             _abi.f64_ptr(direction.reshape(-1)), _abi.f64_ptr(out.reshape(-1))), self.lib)
         return out
 
+    def crossing(self, batch, device=0, precision=_abi.F32):
+        """RayTrace.CheckElementsForCrossingPoint for every photon of `batch`:
+        (element index or -1, SmallestDistance, PointCy)."""
+        n = batch["wavelength"].shape[0]
+        el = np.full(n, -1, dtype=np.int32)
+        dist = np.zeros(n, dtype=np.float64)
+        pts = np.zeros((n, 3), dtype=np.float64)
+        s = batch_struct(batch)
+        _abi.check(self.lib.rtmc_op_crossing(self.handle, int(device), int(precision), n, C.byref(s),
+                                             _abi.i32_ptr(el), _abi.f64_ptr(dist),
+                                             _abi.f64_ptr(pts.reshape(-1))), self.lib)
+        return el, dist, pts
+
     def wavelengths(self):
         cnt = C.c_int64()
         _abi.check(self.lib.rtmc_scene_wavelengths(self.handle, C.byref(cnt), None, 0), self.lib)

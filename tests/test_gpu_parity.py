@@ -129,6 +129,44 @@ def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     assert worst < (2e-6 if name == "C8" else 1e-6), (worst, where)
 
 
+@pytest.mark.parametrize("name", ["C2", "C4", "C8"])
+def test_crossing_operation(scenes, oracle_mod, name):
+    """rtmc_op_crossing (RayTrace.CheckElementsForCrossingPoint) on every photon
+    state of the golden traces' first iterations: float64 finds the checker's
+    element, distance and point; float32 the same element unless two
+    candidates tie within rounding."""
+    g = H.load_trace(name)
+    rt, s = scenes(name)
+    states = _oracle_states(oracle_mod, rt, g, 12)
+    o = oracle_mod.OracleScene.from_raytrace(rt)
+    n = len(g["n_iter"])
+    total = off32 = 0
+    for i in range(12):
+        b = states[i]
+        live = (b["iterations"] == i) & ~np.isin(b["status"], (4, 5, 6))
+        el_o, d_o, p_o = o.crossing(b)
+        el64, d64, p64 = s.crossing(b, precision=_abi.F64)
+        el32, d32, p32 = s.crossing(b, precision=_abi.F32)
+        for k in np.nonzero(live)[0]:
+            total += 1
+            assert el64[k] == el_o[k], (i, k)
+            if el_o[k] >= 0:
+                assert d64[k] == pytest.approx(d_o[k], rel=1e-9)
+                assert np.allclose(p64[k], p_o[k], atol=1e-9)
+            if el32[k] != el_o[k]:
+                off32 += 1
+            elif el_o[k] >= 0:
+                assert d32[k] == pytest.approx(d_o[k], rel=2e-5, abs=2e-6)
+    assert total > 300 and off32 <= max(1, total // 500), (off32, total)
+    # the host method of the same name on one photon
+    ph = rt.Photon
+    ph.Location, ph.Direction = np.array(ph.StartingLocation, float), np.array([0.05, 0.1, -1.0])
+    ph.WasElement = False
+    found = rt.CheckElementsForCrossingPoint()
+    assert found is rt.FirstEl and np.isfinite(rt.SmallestDistance)
+    assert np.allclose(np.asarray(ph.PointCy), ph.Location + rt.SmallestDistance * ph.Direction / np.linalg.norm(ph.Direction), atol=1e-9)
+
+
 def test_rectangle_known_answers_on_gpu(golden_dir):
     """Rectangle.FindIntersections on the constants of the reference's
     TestGeometries.py and on random rectangles, through rtmc_op_intersect."""

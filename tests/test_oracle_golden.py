@@ -197,3 +197,31 @@ def test_shape_known_answers(oracle_mod, golden_dir):
     for v, tm in zip(k["mva_v"], k["mva_tm"]):
         n1, n2 = oracle_mod.vect_axis(v)
         assert np.allclose(n1, tm[:, 1], atol=1e-15) and np.allclose(n2, tm[:, 2], atol=1e-15)
+
+
+@pytest.mark.parametrize("name", ["C2", "C4", "C8"])
+def test_crossing_operation_matches_reference_rows(oracle_mod, name):
+    """CheckElementsForCrossingPoint as a single operation: from the photon
+    state before every recorded iteration it finds the element and distance
+    the reference logged for that iteration."""
+    from raytracer_amd import scene as sc
+    g = H.load_trace(name)
+    rt = H.raytrace_for(name)
+    o = oracle_mod.OracleScene.from_raytrace(rt)
+    n = len(g["n_iter"])
+    batch = sc.new_photon_batch(n)
+    o.step_tape(batch, g["tape"], g["tape_off"], 0, launch=True)
+    rows, ro = g["rows"], g["row_off"]
+    checked = 0
+    for it in range(12):
+        el, dist, pts = o.crossing(batch)
+        for k in range(n):
+            if ro[k] + it < ro[k + 1] and batch["iterations"][k] == it and batch["status"][k] not in (4, 5, 6):
+                r = rows[ro[k] + it]
+                if np.isfinite(r[H.G_HITD]):
+                    assert el[k] == r[H.G_HIT] and dist[k] == pytest.approx(r[H.G_HITD], rel=1e-12), (k, it)
+                else:
+                    assert el[k] == -1 and np.isinf(dist[k])
+                checked += 1
+        o.step_tape(batch, g["tape"], g["tape_off"], 1, launch=False)
+    assert checked > 300
