@@ -117,6 +117,9 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     tally.n_el = sc.n_el; tally.n_bins = (int)sc.lay.n_bins;
     tally.fixed_source = sc.src.wl_mode == 0;
     tally.lane_steps = 0ull; tally.lane_abs_once = 0u;
+#ifdef RTMC_PROFILE_SECTIONS
+    for (int k = 0; k < 4; k++) tally.prof[k] = 0ull;
+#endif
 
     Photon<real> p;
     Rng<real, false> g;
@@ -236,6 +239,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     if (lane == 0) {  // per-wave totals behind the work counter
         atomicAdd(&work[8], cyc_renew); atomicAdd(&work[9], n_renew); atomicAdd(&work[10], lanes_renew);
         atomicAdd(&work[11], cyc_step); atomicAdd(&work[12], n_step); atomicAdd(&work[13], lanes_step);
+        for (int k = 0; k < 4; k++) atomicAdd(&work[14 + k], tally.prof[k]);
     }
 #endif
 
@@ -1061,8 +1065,36 @@ static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, cons
     return sc;
 }
 
+static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                      uint64_t n_photons, rtmc_tallies *out);
+RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device);
+
+// A workgroup counts detector hits in 32-bit LDS words; a launch is kept small
+// enough that no workgroup can come near 2^32 photons.
+static const uint64_t MAX_PHOTONS_PER_LAUNCH = 100000000000ull;
+
 RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
                         uint64_t n_photons, rtmc_tallies *out)
+{
+    uint64_t cap = MAX_PHOTONS_PER_LAUNCH;
+    if (const char *e = getenv("RTMC_MAX_PHOTONS_PER_LAUNCH"))  // tests exercise the splitting with a small value
+        cap = std::max<uint64_t>(1, std::min<uint64_t>(cap, strtoull(e, nullptr, 10)));
+    if (n_photons <= cap) return run_launch(s, device, precision, seed, first_photon, n_photons, out);
+    if (first_photon + n_photons < first_photon) return fail(RTMC_EINVAL, "photon id range wraps");
+    double ms = 0;
+    for (uint64_t done = 0; done < n_photons;) {
+        const uint64_t part = std::min(cap, n_photons - done);
+        int rc = run_launch(s, device, precision, seed, first_photon + done, part, out);
+        if (rc) return rc;
+        ms += rtmc_last_kernel_ms(s, device);
+        done += part;
+    }
+    s->dev[device].last_ms = ms;
+    return RTMC_OK;
+}
+
+static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                      uint64_t n_photons, rtmc_tallies *out)
 {
     if (!s || !out) return fail(RTMC_EINVAL, "null argument");
     if (out->n_elements != s->n_el) return fail(RTMC_EINVAL, "tally block is for %d elements, scene has %d", out->n_elements, s->n_el);
@@ -1100,7 +1132,7 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
                 grid, TRACE_BLOCK, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
     HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
 #ifdef RTMC_PROFILE_SECTIONS
-    HIP_TRY(hipMemsetAsync(p.work, 0, 128, p.stream));
+    HIP_TRY(hipMemsetAsync(p.work, 0, 256, p.stream));
 #else
     HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
 #endif
@@ -1122,13 +1154,16 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     p.last_ms = ms;
 #ifdef RTMC_PROFILE_SECTIONS
     {
-        unsigned long long w[16];
+        unsigned long long w[18];
         HIP_TRY(hipMemcpy(w, p.work, sizeof w, hipMemcpyDeviceToHost));
         fprintf(stderr, "[rtmc] sections: renew %llu passes, %.0f cycles each, %.1f lanes; step %llu passes, %.0f cycles each, %.1f lanes; "
                         "renew share of wave time %.3f\n",
                 w[9], (double)w[8] / (double)std::max(1ull, w[9]), (double)w[10] / (double)std::max(1ull, w[9]),
                 w[12], (double)w[11] / (double)std::max(1ull, w[12]), (double)w[13] / (double)std::max(1ull, w[12]),
                 (double)w[8] / (double)(w[8] + w[11]));
+        fprintf(stderr, "[rtmc] inside step (cycles per pass, lane 0 of each wave): philox %.0f, search %.0f, absorption check %.0f, operation %.0f\n",
+                (double)w[14] / (double)std::max(1ull, w[12]), (double)w[15] / (double)std::max(1ull, w[12]),
+                (double)w[16] / (double)std::max(1ull, w[12]), (double)w[17] / (double)std::max(1ull, w[12]));
     }
 #endif
 

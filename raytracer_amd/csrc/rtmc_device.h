@@ -1020,6 +1020,14 @@ struct LdsTally {
     // per-lane totals, flushed once at the end of the kernel
     unsigned long long lane_steps;
     uint32_t lane_abs_once;
+#ifdef RTMC_PROFILE_SECTIONS
+    unsigned long long prof[4], prof_t;  // cycle stamps inside photon_step (wave-uniform values)
+    __device__ __forceinline__ void stamp_begin() { prof_t = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void stamp(int k) { unsigned long long t = __builtin_readcyclecounter(); prof[k] += t - prof_t; prof_t = t; }
+#else
+    __device__ __forceinline__ void stamp_begin() {}
+    __device__ __forceinline__ void stamp(int) {}
+#endif
     __device__ __forceinline__ void scalar(int which, unsigned long long v = 1ull) { atomicAdd(&acc[which], v); }
     __device__ __forceinline__ void bounce(int el) { atomicAdd(&acc[ACC_SCALARS + el], 1ull); }
     __device__ __forceinline__ void ended(int iter, bool absorbed_once)
@@ -1045,6 +1053,8 @@ struct NoTally {
     __device__ __forceinline__ void bounce(int) {}
     __device__ __forceinline__ void ended(int, bool) {}
     __device__ __forceinline__ void dump(int, int, int, int, bool) {}
+    __device__ __forceinline__ void stamp_begin() {}
+    __device__ __forceinline__ void stamp(int) {}
 };
 
 enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
@@ -1062,9 +1072,12 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     constexpr bool SHAPES = (FEATURES & FEAT_SHAPES) != 0;
     // the variates of this iteration (every lane computes its block together;
     // which words are used depends on what the iteration turns out to be)
+    tally.stamp_begin();
     g.block((uint32_t)p.iter, BLK_STEP);
+    tally.stamp(0);
     real dnorm;
     const Nearest<real> nearest = nearest_valid_hit<FEATURES>(sc, p, dnorm);
+    tally.stamp(1);
     const real best_t = nearest.t;
     const int best_e = nearest.e;
     const bool stale = best_e < 0;
@@ -1109,6 +1122,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
         p.flags |= F_WAS_EL;
     }
 
+    tally.stamp(2);
     // ---- the element's ExecuteOperation -------------------------------------
     {
         const DevElem<real> &el = lds.elems[el_idx];  // per-lane gather from LDS
@@ -1273,6 +1287,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
         set_admissibility(p, type, side, nx * p.Dx + ny * p.Dy + nz * p.Dz);
     }
 
+    tally.stamp(3);
     // ---- RayTrace.py:193-195 ------------------------------------------------
     const bool stop = p.iter >= sc.max_iter - 1;
     p.iter++;

@@ -329,6 +329,19 @@ def test_results_do_not_depend_on_batching(scenes):
         assert whole[key] == parts[key], key
 
 
+def test_long_runs_are_split_into_launches(scenes, monkeypatch):
+    """rtmc_run cuts an id range into several launches when it is very long;
+    with the limit lowered for the test the result is the single-launch one."""
+    rt, s = scenes("C3")
+    whole = s.run(50000, seed=9)
+    monkeypatch.setenv("RTMC_MAX_PHOTONS_PER_LAUNCH", "7000")
+    parts = s.run(50000, seed=9)
+    for key in ("counter", "spectral", "bounce", "energy_fx", "spectrum"):
+        assert np.array_equal(whole[key], parts[key]), key
+    for key in _abi.TALLY_SCALARS:
+        assert whole[key] == parts[key], key
+
+
 def test_empty_and_tiny_runs(scenes):
     rt, s = scenes("C2")
     t = s.run(0, seed=1)
