@@ -88,10 +88,18 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // Philox event and one pass through the direction / polarisation samplers.
 // The grid is sized to the machine, not to n.
 enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
-#ifndef RTMC_RENEW_THRESHOLD
-#define RTMC_RENEW_THRESHOLD 32
+// When to run the renew block.  It costs R (about half a loop iteration)
+// whatever the number of lanes in it, while every lane that waits for it wastes
+// 1/64 of an iteration S per iteration.  Running it every P iterations costs
+// R/P + (waste accumulated over P)/P per iteration, which is smallest when the
+// accumulated waste equals R: the block runs once the lane-iterations spent
+// waiting since the last run reach 64 R/S.  Scenes whose photons end after a few
+// iterations get there every other iteration with half the wave waiting; scenes
+// whose photons live for hundreds of iterations with three or four lanes waiting.
+#ifndef RTMC_RENEW_DEBT
+#define RTMC_RENEW_DEBT 40
 #endif
-constexpr int RENEW_THRESHOLD = RTMC_RENEW_THRESHOLD;  // lanes (of 64) that must be waiting
+constexpr int RENEW_DEBT = RTMC_RENEW_DEBT;  // lane-iterations
 
 // Register budget: the float32 kernels are held to 80 VGPRs so that six waves
 // share a SIMD (three 512-thread workgroups per CU); the loop waits on LDS
@@ -128,6 +136,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     int need = NEED_LAUNCH;
     uint64_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;
+    int idle_debt = 0;  // wave-uniform: lane-iterations spent waiting for the renew block
     const uint32_t lane = threadIdx.x & 63;
 
 #ifdef RTMC_PROFILE_SECTIONS
@@ -139,14 +148,14 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
 #define SECTION_END(acc, cnt, lanes, mask) do {} while (0)
 #endif
     for (;;) {
-        // The renew block costs about half a loop iteration whatever the number of
-        // lanes in it; it waits until enough lanes want it (or nobody can step).
         // (Single exit and no `continue`: with two back edges the compiler copied the
         // whole photon record to other registers and back on every iteration.)
         const unsigned long long want = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
         const unsigned long long stepping = __ballot(need == NEED_NONE);
         if ((want | stepping) == 0ull) break;  // every lane is switched off
-        if (want != 0ull && (__popcll(want) >= RENEW_THRESHOLD || stepping == 0ull)) {
+        idle_debt += __popcll(want);
+        if (want != 0ull && (idle_debt >= RENEW_DEBT || stepping == 0ull)) {
+            idle_debt = 0;
             SECTION_BEGIN();
 #ifdef RTMC_PROFILE_SECTIONS
             const unsigned long long renew_mask = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
