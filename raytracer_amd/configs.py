@@ -13,6 +13,7 @@ that runs the reference itself.
 from __future__ import annotations
 
 import copy
+import os
 
 import numpy as np
 
@@ -20,17 +21,20 @@ AIR_ROW = ["air", 1.0, False, 0.0, 0.0, "blue", False, [0.0, 0.0, 0.0], 0.0, 0.0
            0.0, 0.0, 0.0, 0.0, "0", "0", "0", "0", 0, False, 0.0, 1]
 
 
+EQE_DEMO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "eqe_demo.txt")
+
+
 def dye_row(name, conc_a=1.0, conc_b=0.0, n=1.5, aligned=False, align_s=0.1,
-            align_vect=(0.0, 0.0, 1.0), abs_em_angle=0):
+            align_vect=(0.0, 0.0, 1.0), abs_em_angle=0, fix_dist=False, fix_dist_r=1.0):
     """Material row: Lumogen Red acceptor (+ optional Oxacin donor)."""
     return [name, float(n), True, float(conc_b), float(conc_a), "red", bool(aligned),
             [float(c) for c in align_vect], float(align_s), 5.0,
             0.9, 0.95, 2.5, 6.0, 35731.0, 54000.0,
             "OxacinAbs.txt", "OxacinEm.txt", "LumogenRedAbs.txt", "LumogenRedEm.txt",
-            abs_em_angle, False, 1.0, 1]
+            abs_em_angle, bool(fix_dist), float(fix_dist_r), 1]
 
 
-def _slab_faces(z0, z1, half, mat, edge_types=(4, 4, 4, 4)):
+def _slab_faces(z0, z1, half, mat, edge_types=(4, 4, 4, 4), eqe=""):
     """Six rectangles of one slab: bottom/top interfaces then the four edges.
 
     Order and orientation follow the shipped job (bottom `[mat, air]`, top
@@ -47,7 +51,7 @@ def _slab_faces(z0, z1, half, mat, edge_types=(4, 4, 4, 4)):
     ]
     props = [[2, mat, "air"], [2, "air", mat]]
     for t in edge_types:
-        props.append([4, 0, 0, ""] if t == 4 else [1])
+        props.append([4, 0, 0, eqe] if t == 4 else [1])
     sizes = [[half, half], [half, half]] + [[half, hw]] * 4
     return elements, props, [list(s) for s in sizes]
 
@@ -80,21 +84,22 @@ SUN = "Sun spectrum AG15g"
 
 def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=False,
              aligned=False, align_s=0.1, abs_em_angle=0, respect_pol=True,
-             direction=(0.0, 0.0, -1.0)):
+             direction=(0.0, 0.0, -1.0), eqe="", scale=1.0, fix_dist=False, fix_dist_r=1.0):
     """One 5 x 5 cm dye-doped slab, source at (0, 2, 1) pointing down at 460 nm.
 
     thickness 0.012 + enclosed False is the shipped job's geometry."""
     name = "LRO" if donor else "LR"
-    els, props, sizes = _slab_faces(0.0, thickness, 2.5, name)
+    els, props, sizes = _slab_faces(0.0, thickness, 2.5, name, eqe=eqe)
     if enclosed:
         zc = 0.5 * thickness
         e2, p2, s2 = _dump_box(0.0, 0.0, zc, 4.0, 2.0)
         els, props, sizes = els + e2, props + p2, sizes + s2
     mats = [copy.deepcopy(AIR_ROW),
             dye_row(name, conc_a=1.0, conc_b=1.0 if donor else 0.0, aligned=aligned,
-                    align_s=align_s, abs_em_angle=abs_em_angle)]
+                    align_s=align_s, abs_em_angle=abs_em_angle, fix_dist=fix_dist,
+                    fix_dist_r=fix_dist_r)]
     photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460,
-                     "air", direction, respect_pol=respect_pol)
+                     "air", direction, respect_pol=respect_pol, scale=scale)
     return {
         "Elements": np.array(els, dtype=np.float64),
         "ElementProperties": props,
@@ -199,6 +204,10 @@ CONFIGS = {
                           abs_em_angle=10, respect_pol=False)),
     # every shape (cylinder, circle, triangle, rectangle) and type (interface, lens, mirror, detector)
     "C8": (rod_job, dict()),
+    # the options the other configurations leave at their defaults: detectors with a
+    # quantum-efficiency table, fixed donor-acceptor distance for the back transfer, a scale factor
+    "C9": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, eqe=EQE_DEMO, scale=2.0,
+                          fix_dist=True, fix_dist_r=3.0)),
 }
 
 

@@ -46,7 +46,7 @@ def test_f64_tape_replay_matches_reference(scenes, name):
     assert len(bad) <= allowed, "photons off the reference path: %s (worst %.2e)" % (bad[:10], worst)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
 def test_f32_tape_replay_follows_reference(scenes, name):
     """float32 kernels on the reference's variates: same discrete path for
     (nearly) every photon and vectors within 2e-5 after a whole trajectory
@@ -74,7 +74,7 @@ def _oracle_states(oracle_mod, rt, g, max_iter):
     return states
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
 def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     """One loop iteration from identical input state and identical variates:
     float32 positions, directions, polarisation and free path agree with the
@@ -224,7 +224,7 @@ def _sigma(n, p):
     return max(1.0, (n * p * (1 - p)) ** 0.5)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
 def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     """Same seed, same Philox stream, float64 on both sides: every integer
     tally is identical except for the odd photon that passes within rounding
@@ -246,7 +246,7 @@ def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     assert np.abs(gpu["energy_fx"].astype(np.int64) - cpu["energy_fx"].astype(np.int64)).max() <= 8 << 24
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
 def test_f32_follows_f64_photon_for_photon(scenes, name):
     """float32 production kernels against the float64 instantiation on the
     same 5e6 photons: a photon changes fate only when it passes within
@@ -265,7 +265,7 @@ def test_f32_follows_f64_photon_for_photon(scenes, name):
     assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= n // 2000 + slack + (int(b["n_steps"]) // 1000 if name == "C8" else 0)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C1_open"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C1_open"])
 def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     """Production path against the reference's own seeded runs
     (tests/golden/ref_tallies.json): every detector count, internal
@@ -281,6 +281,8 @@ def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     assert gpu["n_photons"] == n_gpu
     ref_counter = np.sum([r["counter"] for r in runs], axis=0)
     checks = [("element %d" % i, ref_counter[i], gpu["counter"][i]) for i in range(len(ref_counter))]
+    ref_spectral = np.sum([r["spectral"] for r in runs], axis=0)   # detection-efficiency draws, Elements.py:161-165
+    checks += [("spectral %d" % i, ref_spectral[i], gpu["spectral"][i]) for i in range(len(ref_spectral))]
     checks.append(("ic", sum(r["ic"] for r in runs), gpu["n_internal_converted"]))
     checks.append(("absorbed_once", sum(r["absorbed_once"] for r in runs), gpu["n_absorbed_once"]))
     checks.append(("capped", sum(r["capped"] for r in runs), gpu["n_capped"]))
@@ -295,7 +297,7 @@ def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     assert abs(eta_ref - eta_gpu) <= 3 * _sigma(n_ref, eta_gpu) / n_ref * (1 + n_ref / n_gpu) ** 0.5
 
 
-@pytest.mark.parametrize("name", ["C2", "C3", "C6", "C7"])
+@pytest.mark.parametrize("name", ["C2", "C3", "C6", "C7", "C9"])
 def test_production_tallies_against_reference_order_sampling_at_scale(scenes, oracle_mod, name):
     """A sharper version of the 3-sigma test: 2e7 float32 GPU photons against
     4e6 photons of the CPU checker drawing where and how the reference draws
@@ -308,6 +310,7 @@ def test_production_tallies_against_reference_order_sampling_at_scale(scenes, or
     cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n_cpu, seed=7, threads=16,
                                                                reference_order=True)
     pairs = [(gpu["counter"][i], cpu["counter"][i]) for i in range(s.n_elements)]
+    pairs += [(gpu["spectral"][i], cpu["spectral"][i]) for i in range(s.n_elements)]
     pairs += [(gpu[k], cpu[k]) for k in ("n_internal_converted", "n_absorbed_once")]
     for x, y in pairs:
         pg, pc = float(x) / n_gpu, float(y) / n_cpu

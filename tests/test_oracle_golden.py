@@ -109,7 +109,7 @@ def test_rectangle_known_answers(oracle_mod, golden_dir):
 
 
 @pytest.mark.parametrize("name,n", [("C2", 600000), ("C3", 600000), ("C4", 200000), ("C5", 600000),
-                                    ("C6", 600000), ("C7", 600000), ("C8", 12000)])
+                                    ("C6", 600000), ("C7", 600000), ("C8", 12000), ("C9", 600000)])
 def test_event_layout_samplers_follow_the_reference_laws(oracle_mod, name, n):
     """The Philox event layout samples directions, polarisations and the
     aligned-dye emission angle with other constructions than the reference
@@ -122,6 +122,7 @@ def test_event_layout_samplers_follow_the_reference_laws(oracle_mod, name, n):
     a = o.run_threads(n, seed=21, threads=8)
     b = o.run_threads(n, seed=21, threads=8, reference_order=True)
     pairs = [(a["counter"][i], b["counter"][i]) for i in range(o.n_elements)]
+    pairs += [(a["spectral"][i], b["spectral"][i]) for i in range(o.n_elements)]
     pairs += [(a[k], b[k]) for k in ("n_internal_converted", "n_absorbed_once", "n_capped")]
     for x, y in pairs:
         pa, pb = float(x) / n, float(y) / n
