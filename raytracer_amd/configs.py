@@ -174,6 +174,35 @@ def rod_job(n_photons=10000):
     }
 
 
+def rotated_job(base="C2", axis=(0.3, -0.5, 0.8), angle=0.7, n_photons=10000, **kwargs):
+    """A rectangle-only job turned rigidly about `axis` by `angle` radians:
+    every plane gets a general orientation (explicit in-plane axes keep the
+    rectangles' footprints), the physics stays that of the base job."""
+    from .Geometries import Rectangle
+    builder, kw = CONFIGS[base]
+    job = builder(**dict(kw, n_photons=n_photons, **kwargs))
+    k = np.asarray(axis, dtype=np.float64)
+    k /= np.linalg.norm(k)
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K)
+    els = np.array(job["Elements"], dtype=np.float64)
+    sizes = []
+    for i in range(len(els)):
+        assert job["ElementGeometry"][i] == 1
+        size = job["ElementSize"][i]
+        rect = Rectangle(size[0], size[1], els[i][0], els[i][1], None,
+                         size[2] if len(size) > 2 else [0, 0, 0])
+        els[i][0] = R @ els[i][0]
+        els[i][1] = R @ rect.DirectionVector
+        sizes.append([size[0], size[1], list(R @ rect.e1)])
+    job["Elements"] = els
+    job["ElementSize"] = sizes
+    ph = job["Photon"]
+    ph[1] = [float(c) for c in R @ np.asarray(ph[1])]
+    ph[6] = [float(c) for c in R @ np.asarray(ph[6])]
+    return job
+
+
 def synthetic_am15():
     """Two-column stand-in for the sun table the reference expects in
     `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with
@@ -206,6 +235,8 @@ CONFIGS = {
     "C8": (rod_job, dict()),
     # the options the other configurations leave at their defaults: detectors with a
     # quantum-efficiency table, fixed donor-acceptor distance for the back transfer, a scale factor
+    # C2 turned rigidly: no plane is axis-aligned, every element takes the general hit test
+    "C2r": (rotated_job, dict(base="C2")),
     "C9": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, eqe=EQE_DEMO, scale=2.0,
                           fix_dist=True, fix_dist_r=3.0)),
 }

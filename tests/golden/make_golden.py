@@ -317,7 +317,7 @@ def pack_traces(photons, tape):
 def gen_traces(ref):
     plan = {"C1_open": (40, 11, 150), "C1": (60, 12, 400), "C2": (120, 13, 400),
             "C3": (160, 14, 400), "C4": (120, 15, 400), "C5": (120, 16, 400),
-            "C6": (150, 17, 400), "C7": (200, 18, 400), "C8": (400, 19, 400), "C9": (250, 20, 400)}
+            "C6": (150, 17, 400), "C7": (200, 18, 400), "C8": (400, 19, 400), "C9": (250, 20, 400), "C2r": (120, 21, 400)}
     only = os.environ.get("GOLDEN_ONLY")
     if only:
         plan = {k: v for k, v in plan.items() if k in only.split(",")}

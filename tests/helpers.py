@@ -8,7 +8,7 @@ from raytracer_amd import RayTrace, configs
 from raytracer_amd import scene as sc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TRACE_CONFIGS = ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"]
+TRACE_CONFIGS = ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"]
 
 # columns of a golden trace row (tests/golden/make_golden.py ROW_FIELDS)
 G_L, G_D, G_E = slice(0, 3), slice(3, 6), slice(6, 9)

@@ -46,7 +46,7 @@ def test_f64_tape_replay_matches_reference(scenes, name):
     assert len(bad) <= allowed, "photons off the reference path: %s (worst %.2e)" % (bad[:10], worst)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"])
 def test_f32_tape_replay_follows_reference(scenes, name):
     """float32 kernels on the reference's variates: same discrete path for
     (nearly) every photon and vectors within 2e-5 after a whole trajectory
@@ -74,7 +74,7 @@ def _oracle_states(oracle_mod, rt, g, max_iter):
     return states
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"])
 def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     """One loop iteration from identical input state and identical variates:
     float32 positions, directions, polarisation and free path agree with the
@@ -224,7 +224,7 @@ def _sigma(n, p):
     return max(1.0, (n * p * (1 - p)) ** 0.5)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"])
 def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     """Same seed, same Philox stream, float64 on both sides: every integer
     tally is identical except for the odd photon that passes within rounding
@@ -240,13 +240,20 @@ def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     for key in ("n_steps", "n_absorbed_once", "n_absorptions", "n_internal_converted", "n_dumped",
                 "n_capped", "n_stale_steps"):
         moved += abs(int(gpu[key]) - int(cpu[key]))
-    assert moved <= 8, moved
+    # C2r: every photon meets the tilted slab at exactly normal incidence.  The reference takes
+    # arccos(-D.n) of unnormalised vectors (Elements.py:87); when rounding lifts |D.n| above 1
+    # that is NaN, the reflectance is NaN and `rand() > R` is false, so the photon is reflected
+    # (and then again at every later normal incidence).  The checker reproduces this, the
+    # kernels use the physical reflectance; the photons that cross the slab unabsorbed and
+    # are reflected at its far face (1 in 2e4) therefore differ.
+    slack = 8 if name != "C2r" else n // 1000
+    assert moved <= slack, moved
     # detector spectra: same photons in the same 1-nm bins
-    assert np.abs(gpu["spectrum"].astype(np.int64) - cpu["spectrum"].astype(np.int64)).sum() <= 8
-    assert np.abs(gpu["energy_fx"].astype(np.int64) - cpu["energy_fx"].astype(np.int64)).max() <= 8 << 24
+    assert np.abs(gpu["spectrum"].astype(np.int64) - cpu["spectrum"].astype(np.int64)).sum() <= slack
+    assert np.abs(gpu["energy_fx"].astype(np.int64) - cpu["energy_fx"].astype(np.int64)).max() <= slack << 24
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"])
 def test_f32_follows_f64_photon_for_photon(scenes, name):
     """float32 production kernels against the float64 instantiation on the
     same 5e6 photons: a photon changes fate only when it passes within
@@ -316,6 +323,24 @@ def test_production_tallies_against_reference_order_sampling_at_scale(scenes, or
         pg, pc = float(x) / n_gpu, float(y) / n_cpu
         sig = max((pg * (1 - pg) * (1.0 / n_gpu + 1.0 / n_cpu)) ** 0.5, 1.0 / n_cpu)
         assert abs(pg - pc) <= 4.5 * sig, (name, pg, pc, sig)
+
+
+def test_rigid_rotation_leaves_the_tallies_unchanged(scenes):
+    """C2r is C2 turned as a whole: every rectangle goes through the
+    general-orientation hit test instead of the axis-aligned one, and the
+    tallies of 2e7 photons agree with C2's within 4.5 sigma."""
+    _, a = scenes("C2")
+    _, b = scenes("C2r")
+    n = 20000000
+    ta, tb = a.run(n, seed=31), b.run(n, seed=32)
+    pairs = [(ta["counter"][i], tb["counter"][i]) for i in range(a.n_elements)]
+    pairs += [(ta["bounce"][i], tb["bounce"][i]) for i in range(2)]
+    pairs += [(ta[k], tb[k]) for k in ("n_internal_converted", "n_absorbed_once")]
+    for x, y in pairs:
+        pa, pb = float(x) / n, float(y) / n
+        pm = 0.5 * (pa + pb)
+        sig = max((2 * pm * abs(1 - pm) / n) ** 0.5, 1.0 / n) if pm <= 1 else (2 * pm / n) ** 0.5 * 3
+        assert abs(pa - pb) <= 4.5 * sig, (x, y)
 
 
 def test_results_do_not_depend_on_batching(scenes):
