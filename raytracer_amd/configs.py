@@ -110,22 +110,23 @@ def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=Fal
     }
 
 
-def stacked_job(n_photons=10000):
-    """Three stacked slabs (0.3 thick, 0.05 air gaps); each slab has mirrors on
-    three edges and a detector on the +x edge; isotropic source above; closed
-    detector box around everything.  Element order: slab 1 (top), slab 2,
-    slab 3, box."""
+def stacked_job(n_photons=10000, n_slabs=3):
+    """Stacked slabs (0.3 thick, 0.05 air gaps; three by default); each slab has
+    mirrors on three edges and a detector on the +x edge; isotropic source
+    above; closed detector box around everything.  Element order: slab 1
+    (top), slab 2, ..., box."""
     els, props, sizes = [], [], []
-    tops = [0.7, 0.35, 0.0]
-    names = ["LR", "LRO", "LR"]
+    tops = [0.35 * (n_slabs - 1 - k) for k in range(n_slabs)]
+    names = [("LR", "LRO")[k % 2] for k in range(n_slabs)]
     for z0, nm in zip(tops, names):
         e, p, s = _slab_faces(z0, z0 + 0.3, 2.5, nm, edge_types=(4, 1, 1, 1))
         els, props, sizes = els + e, props + p, sizes + s
-    e, p, s = _dump_box(0.0, 0.0, 0.5, 4.0, 2.0)
+    top = tops[0] + 0.3
+    e, p, s = _dump_box(0.0, 0.0, 0.5, 4.0, 2.0 if n_slabs == 3 else top + 1.5)
     els, props, sizes = els + e, props + p, sizes + s
     mats = [copy.deepcopy(AIR_ROW), dye_row("LR"), dye_row("LRO", conc_b=1.0)]
-    photon = _photon(n_photons, (0.0, 0.0, 2.0), ISOTROPIC, FIXED_WL, 460, "air",
-                     (0.0, 0.0, -1.0))
+    photon = _photon(n_photons, (0.0, 0.0, 2.0 if n_slabs == 3 else top + 1.0), ISOTROPIC, FIXED_WL, 460,
+                     "air", (0.0, 0.0, -1.0))
     return {
         "Elements": np.array(els, dtype=np.float64),
         "ElementProperties": props,

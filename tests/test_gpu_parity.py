@@ -357,6 +357,39 @@ def test_results_do_not_depend_on_batching(scenes):
         assert whole[key] == parts[key], key
 
 
+def test_large_scenes(oracle_mod):
+    """102 elements (16 stacked slabs + box): float64 kernels against the
+    checker photon for photon.  252 elements (41 slabs; the library takes up
+    to 255, the float64 tables of this one no longer fit the LDS): float32
+    against the checker.  One slab more is refused with a message."""
+    from raytracer_amd import RayTrace, configs
+    n = 40000
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.stacked_job(10, n_slabs=16))
+    s = rt.Scene()
+    assert s.n_elements == 102
+    g64 = s.run(n, seed=4, precision=_abi.F64)
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=4, threads=8)
+    moved = sum(int(np.abs(g64[k].astype(np.int64) - cpu[k].astype(np.int64)).sum()) for k in ("counter", "spectral"))
+    assert g64["n_photons"] == n and moved <= 8, moved
+    s.close()
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.stacked_job(10, n_slabs=41))
+    s = rt.Scene()
+    assert s.n_elements == 252
+    with pytest.raises(_abi.RtmcError, match="LDS"):
+        s.run(10, seed=4, precision=_abi.F64)
+    g32 = s.run(n, seed=4)
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=4, threads=8)
+    assert g32["n_photons"] == n
+    assert int(np.abs(g32["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()) <= n // 2000
+    s.close()
+    too_many = RayTrace.RayTrace(demo_scene=False)
+    too_many.LoadJob(configs.stacked_job(10, n_slabs=42))
+    with pytest.raises(_abi.RtmcError, match="elements"):
+        too_many.Scene()
+
+
 def test_long_runs_are_split_into_launches(scenes, monkeypatch):
     """rtmc_run cuts an id range into several launches when it is very long;
     with the limit lowered for the test the result is the single-launch one."""
