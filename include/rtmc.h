@@ -241,9 +241,10 @@ void rtmc_scene_destroy(rtmc_scene *scene);
 
 /* Replaces the photon loop of RayTrace.runSimulation (RayTrace.py:166-201)
  * for photon ids [first_photon, first_photon + n_photons).  Variates come
- * from Philox4x32-10 keyed by `seed` and counted by (photon id, draw event),
- * so the result does not depend on how a job is split into calls or devices.
- * Blocks until the tallies are on the host. */
+ * from Philox4x32-10 keyed by `seed` and counted by (photon id, loop iteration,
+ * purpose of the draw), so the result does not depend on how a job is split
+ * into calls or devices.  Ranges longer than 1e11 photons are traced in
+ * several launches.  Blocks until the tallies are on the host. */
 int rtmc_run(rtmc_scene *scene, int device, int precision, uint64_t seed,
              uint64_t first_photon, uint64_t n_photons, rtmc_tallies *out);
 
