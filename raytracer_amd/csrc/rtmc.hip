@@ -110,7 +110,8 @@ constexpr int RENEW_DEBT = RTMC_RENEW_DEBT;  // lane-iterations
 #define RTMC_TRACE_WAVES 6
 #endif
 template <typename real, int FEATURES>
-__global__ void __launch_bounds__(TRACE_BLOCK, (sizeof(real) == 4 ? RTMC_TRACE_WAVES : 1))
+__global__ void __launch_bounds__(TRACE_BLOCK)
+__attribute__((amdgpu_waves_per_eu((sizeof(real) == 4 ? RTMC_TRACE_WAVES : 1), (sizeof(real) == 4 ? RTMC_TRACE_WAVES : 4))))
 trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
              unsigned long long *work)
 {
@@ -169,12 +170,12 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 const bool in_donor = absorbed_by_donor<ALIGNED>(m, a, p, g);
                 uint32_t v_lambda;
                 const int outcome = fret_decide(m, g, in_donor, (uint32_t)p.iter, v_lambda);
-                if (outcome == 1) {
-                    p.wid = m.widD_off + cdf_pick_guided(lds.cdf + m.cdfD_off, m.cdfD_len, lds.guide + m.gD_off, v_lambda);
-                    p.status = RTMC_ST_REEMITTED_DONOR;
-                } else if (outcome == 2) {
-                    p.wid = m.widA_off + cdf_pick_guided(lds.cdf + m.cdfA_off, m.cdfA_len, lds.guide + m.gA_off, v_lambda);
-                    p.status = RTMC_ST_REEMITTED_ACCEPTOR;
+                if (outcome != 0) {  // one pick for both dyes: the table is chosen per lane
+                    const bool donor = outcome == 1;
+                    const int off = donor ? m.cdfD_off : m.cdfA_off, len = donor ? m.cdfD_len : m.cdfA_len;
+                    const int goff = donor ? m.gD_off : m.gA_off, woff = donor ? m.widD_off : m.widA_off;
+                    p.wid = woff + cdf_pick_guided(lds.cdf + off, len, lds.guide + goff, v_lambda);
+                    p.status = donor ? RTMC_ST_REEMITTED_DONOR : RTMC_ST_REEMITTED_ACCEPTOR;
                 } else {
                     p.status = RTMC_ST_INTERNAL_CONVERTED;
                 }
@@ -216,15 +217,13 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 // an emitting photon's iteration count has already moved on
                 const uint32_t emit_iter = (uint32_t)p.iter - 1u;
                 g.block(launching ? 0u : emit_iter, launching ? BLK_LAUNCH : BLK_EMIT);
-                if (launching) {
-                    renew_launch(sc, lds, p, g);
-                } else {
-                    const DevMat<real> &m = lds.mats[p.mat];
-                    if (ALIGNED && (m.flags & 2) && p.status == RTMC_ST_REEMITTED_ACCEPTOR)
-                        renew_emit_aligned(hot, lds, m, p, g, emit_iter);
-                    else
-                        renew_emit<ALIGNED>(hot, lds, m, p, g);
-                }
+                bool special = false;  // fluorescence of an aligned acceptor
+                if (ALIGNED && emitting)
+                    special = (lds.mats[p.mat].flags & 2) && p.status == RTMC_ST_REEMITTED_ACCEPTOR;
+                if (special)
+                    renew_emit_aligned(hot, lds, lds.mats[p.mat], p, g, emit_iter);
+                else
+                    renew_photon<ALIGNED>(sc, hot, lds, p, g, launching);
                 need = NEED_NONE;
             }
             SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);

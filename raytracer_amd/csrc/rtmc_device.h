@@ -708,34 +708,34 @@ __device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_
     Ez = c * (-sg * Dx) + s * (-Dy);
 }
 
-// Launch (PhotonObject.py:49-97) with one event: words 0,1 direction (hemisphere
+// Launch (PhotonObject.py:49-97): words 0,1 of the block direction (hemisphere
 // source only), 2 polarisation angle, 3 wavelength (spectrum source only).
-template <typename real>
-__device__ __forceinline__ void renew_launch(SceneArg<real> sc, const Lds<real> &lds, Photon<real> &p,
-                                             Rng<real, false> &g)
+// Re-emission (MonteCarloFRET.py:92-105,170-175 + PhotonObject.py:250/258):
+// words 0,1 direction, 2 polarisation angle, 3 free path.
+// Launch or re-emission of the lanes of a wave in one pass: the direction and
+// polarisation samplers are run once for both kinds of lane.
+template <bool ALIGNED, typename real>
+__device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<real> &hot, const Lds<real> &lds,
+                                             Photon<real> &p, Rng<real, false> &g, bool launching)
 {
     const auto &s = sc.src;
-    p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
-    if (s.dir_mode == 1) {
-        sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
-        apply_source_frame(s, p);
-    } else {
-        p.Dx = s.dir[0]; p.Dy = s.dir[1]; p.Dz = s.dir[2];
+    const bool hemisphere = s.dir_mode == 1;
+    real dx = s.dir[0], dy = s.dir[1], dz = s.dir[2];
+    if (!launching | hemisphere) sphere_direction(g.uniform(0), g.uniform(1), dx, dy, dz);
+    p.Dx = dx; p.Dy = dy; p.Dz = dz;
+    if (launching & hemisphere) apply_source_frame(s, p);
+    perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
+    // (The free path is stored unconditionally: an if/else that stores to a different
+    // member in each arm is merged into one store through a selected address, which
+    // keeps those members of the photon record in scratch memory.)
+    real dist = real(0);
+    if (!launching) dist = free_path<ALIGNED>(hot, lds, p.mat, lds.mats[p.mat].abs_slot, p, g.expo(3));
+    if (launching) {
+        p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
+        p.wid = s.wl_mode == 1 ? cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3)) : s.wid_fixed;
+        init_photon_common(sc, p);
     }
-    p.wid = s.wl_mode == 1 ? cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3)) : s.wid_fixed;
-    perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
-    init_photon_common(sc, p);
-}
-
-// Re-emission (MonteCarloFRET.py:92-105,170-175 + PhotonObject.py:250/258)
-// with one event: words 0,1 direction, 2 polarisation angle, 3 free path.
-template <bool ALIGNED, typename real>
-__device__ __forceinline__ void renew_emit(const HotScene<real> &sc, const Lds<real> &lds, const DevMat<real> &m,
-                                           Photon<real> &p, Rng<real, false> &g)
-{
-    sphere_direction(g.uniform(0), g.uniform(1), p.Dx, p.Dy, p.Dz);
-    perpendicular(p.Dx, p.Dy, p.Dz, g.uniform(2), p.Ex, p.Ey, p.Ez);
-    p.dist = free_path<ALIGNED>(sc, lds, p.mat, m.abs_slot, p, g.expo(3));
+    p.dist = dist;
 }
 
 // Fluorescence of an aligned acceptor (MonteCarloFRET.py:124-162) with two
