@@ -390,6 +390,38 @@ def test_large_scenes(oracle_mod):
         too_many.Scene()
 
 
+def test_reference_demo_scene(oracle_mod):
+    """The 17-element scene the reference builds in its constructor
+    (RayTrace.py:21-45: mirror box, tilted interface box, cylinder detector,
+    triangle mirror, circular lens).  Its own photon cannot be launched (the
+    constructor call predates the Photon signature, PhotonObject.py:9), so a
+    hemispherical 450 nm source is put at its start point.  float64 kernels
+    against the checker photon for photon."""
+    from raytracer_amd import RayTrace, PhotonObject
+    rt = RayTrace.RayTrace()
+    assert len(rt.OpticalElements) == 17
+    air = rt.Photon.StartingMaterial
+    rt.Photon = PhotonObject.Photon(Location=[-0.5, -0.5, -0.1], EmissionMode="Directional Isotropic",
+                                    EmissionDirection=[0.3, 0.2, 1.0], EmissionWavelengthType="fixed",
+                                    StartingWavelength=450.0, StartingMaterial=air,
+                                    StartingLocation=[-0.5, -0.5, -0.1])
+    rt.CreateOpticalElementList()
+    s = rt.Scene()
+    n = 4000
+    g64 = s.run(n, seed=6, precision=_abi.F64)
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=6, threads=8)
+    assert g64["n_photons"] == n
+    assert g64["n_dumped"] + g64["n_capped"] + g64["n_lost"] == n
+    # a closed mirror box: photons bounce until they meet the detector tube; a
+    # path that differs once stays different, so compare fates, not bounce counts
+    assert abs(int(g64["counter"][14]) - int(cpu["counter"][14])) <= 4
+    assert abs(int(g64["n_capped"]) - int(cpu["n_capped"])) <= 4
+    assert abs(int(g64["n_steps"]) - int(cpu["n_steps"])) <= 5 * 10001
+    g32 = s.run(n, seed=6)
+    assert abs(int(g32["counter"][14]) - int(cpu["counter"][14])) <= 5 * (n * 0.25) ** 0.5
+    s.close()
+
+
 def test_long_runs_are_split_into_launches(scenes, monkeypatch):
     """rtmc_run cuts an id range into several launches when it is very long;
     with the limit lowered for the test the result is the single-launch one."""
