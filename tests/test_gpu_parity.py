@@ -272,7 +272,7 @@ def test_f32_follows_f64_photon_for_photon(scenes, name):
     assert abs(int(a["n_steps"]) - int(b["n_steps"])) <= n // 2000 + slack + (int(b["n_steps"]) // 1000 if name == "C8" else 0)
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C1_open"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r", "C1_open"])
 def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     """Production path against the reference's own seeded runs
     (tests/golden/ref_tallies.json): every detector count, internal
