@@ -19,7 +19,7 @@ from oracle import oracle  # noqa: E402
 PEAK = 157.3e12
 n_default = float(sys.argv[1]) if len(sys.argv) > 1 else 1e8
 rows = []
-for name in ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8"]:
+for name in ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"]:
     rt = H.raytrace_for(name)
     s = rt.Scene()
     n = int(n_default if name not in ("C1_open", "C8") else n_default / 50)
