@@ -524,7 +524,7 @@ struct rtmc_scene {
     std::vector<int32_t> el_eqe;    // per element: eqe table or -1
     DeviceImage<float> img32;
     DeviceImage<double> img64;
-    std::mutex mu;
+    mutable std::mutex mu;  // guards `dev`
     std::map<int, PerDevice> dev;
 };
 
@@ -936,13 +936,12 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
 
 static void free_device(PerDevice &p)
 {
-    if (!p.ready) return;
-    (void)hipFree(p.ro_block);
-    (void)hipFree(p.rw_block);
+    if (p.ro_block) (void)hipFree(p.ro_block);
+    if (p.rw_block) (void)hipFree(p.rw_block);
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
     if (p.stream) (void)hipStreamDestroy(p.stream);
-    p.ready = false;
+    p = PerDevice();
 }
 
 RTMC_API void rtmc_scene_destroy(rtmc_scene *s)
@@ -979,7 +978,16 @@ static const void *trace_function(int features)
     }
 }
 
+// Puts the caller's current device back when an entry point returns.
+struct DeviceGuard {
+    int previous = -1;
+    DeviceGuard() { if (hipGetDevice(&previous) != hipSuccess) previous = -1; }
+    ~DeviceGuard() { if (previous >= 0) (void)hipSetDevice(previous); }
+};
+
 // upload the scene to `device` on first use; leaves that device current
+static int init_device(rtmc_scene *s, int device, PerDevice &p);
+
 static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
 {
     int count = 0;
@@ -990,6 +998,13 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
     PerDevice &p = s->dev[device];
     *out = &p;
     if (p.ready) return RTMC_OK;
+    const int rc = init_device(s, device, p);
+    if (rc) free_device(p);  // nothing half-built stays behind; the next call starts over
+    return rc;
+}
+
+static int init_device(rtmc_scene *s, int device, PerDevice &p)
+{
     HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p.ev0));
     HIP_TRY(hipEventCreate(&p.ev1));
@@ -1097,7 +1112,10 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
         ms += rtmc_last_kernel_ms(s, device);
         done += part;
     }
-    s->dev[device].last_ms = ms;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->dev[device].last_ms = ms;
+    }
     return RTMC_OK;
 }
 
@@ -1110,6 +1128,7 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
         return fail(RTMC_EINVAL, "tally block has a null array");
     if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
     if (first_photon + n_photons < first_photon) return fail(RTMC_EINVAL, "photon id range wraps");
+    DeviceGuard restore_device;
     PerDevice *pp;
     int rc = prepare_device(s, device, &pp);
     if (rc) return rc;
@@ -1211,6 +1230,7 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
 RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device)
 {
     if (!s) return -1.0;
+    std::lock_guard<std::mutex> lock(s->mu);
     auto it = s->dev.find(device);
     return it == s->dev.end() ? -1.0 : it->second.last_ms;
 }
@@ -1256,6 +1276,7 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
         if (tape_off[k + 1] < tape_off[k]) return fail(RTMC_EINVAL, "tape offsets must ascend");
         if (tape_off[k + 1] - tape_off[k] > 0x7FFFFFFFull) return fail(RTMC_ELIMIT, "tape segment too long");
     }
+    DeviceGuard restore_device;
     PerDevice *pp;
     int rc = prepare_device(s, device, &pp);
     if (rc) return rc;
@@ -1369,6 +1390,7 @@ RTMC_API int rtmc_op_intersect(rtmc_scene *s, int device, int precision, uint32_
     if (!s || !loc || !dir || !out_points) return fail(RTMC_EINVAL, "null argument");
     if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
     if (n == 0) return RTMC_OK;
+    DeviceGuard restore_device;
     PerDevice *pp;
     int rc = prepare_device(s, device, &pp);
     if (rc) return rc;
