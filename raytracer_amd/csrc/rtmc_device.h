@@ -1206,7 +1206,9 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
                 real rs = (a1 - a2) * M<real>::rcp(a1 + a2);
                 real rp = (b1 - b2) * M<real>::rcp(b1 + b2);
                 real R_perp = rs * rs, R_par = rp * rp;
-                normalize3(p.Ex, p.Ey, p.Ez);
+                // Elements.py:93-94 normalises E here; it already is a unit vector (every rotation and
+                // every sampler ends with a normalisation), so only the float64 instantiation repeats it
+                if (M<real>::has_self_hit_eps) normalize3(p.Ex, p.Ey, p.Ez);
                 real kx = sgn * (p.Dy * nz - p.Dz * ny), ky = sgn * (p.Dz * nx - p.Dx * nz),
                      kz = sgn * (p.Dx * ny - p.Dy * nx);
                 real k2 = kx * kx + ky * ky + kz * kz;
