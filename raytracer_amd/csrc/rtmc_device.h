@@ -941,19 +941,53 @@ __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real 
     best.e = ok ? index : best.e;
 }
 
+// The float32 form of axis_hit + consider for one record.  The five conditions
+// narrow the execution mask one compare after the other and the two moves then
+// update the running minimum under the narrowed mask: no mask algebra on the
+// scalar unit, which this loop otherwise keeps as busy as the vector unit.
+// `ta` carries the admissibility test as a sign: t * adm_q + bias, bias > 0
+// when every candidate is admissible.
+__device__ __forceinline__ void consider_axis_f32(Nearest<float> &best, const HitRec<float> &r, float inv_dk,
+                                                  float m_lk, float Li, float Di, float Lj, float Dj, float adm_q,
+                                                  float adm_bias, int skip)
+{
+    const float t = r.p0 * inv_dk + m_lk;
+    const float di = (Li + t * Di) - r.ci, dj = (Lj + t * Dj) - r.cj;
+    const float ta = t * adm_q + adm_bias;
+    unsigned long long saved;
+    asm("s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_le_f32_e64 vcc, |%[di]|, %[hi]\n\t"
+        "v_cmpx_le_f32_e64 vcc, |%[dj]|, %[hj]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, 0, %[ta]\n\t"
+        "v_cmpx_ne_u32_e32 vcc, %[idx], %[skip]\n\t"
+        "v_cmpx_lt_f32_e64 vcc, |%[t]|, |%[bt]|\n\t"
+        "v_mov_b32_e32 %[bt], %[t]\n\t"
+        "v_mov_b32_e32 %[be], %[idx]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [bt] "+v"(best.t), [be] "+v"(best.e), [sv] "=&s"(saved)
+        : [di] "v"(di), [dj] "v"(dj), [hi] "s"(r.hi), [hj] "s"(r.hj), [ta] "v"(ta), [idx] "s"(r.index),
+          [skip] "v"(skip), [t] "v"(t)
+        : "vcc");
+}
+
 // One group of axis-aligned rectangles, one chunk of records per scalar fetch.
 template <typename real>
 __device__ __forceinline__ void scan_axis_group(const HitChunk<real> *chunks, int count, real inv_dk, real m_lk,
                                                 real Li, real Di, real Lj, real Dj, real adm_q, bool adm_all,
                                                 int skip, real dnorm, Nearest<real> &best)
 {
+    [[maybe_unused]] const real adm_bias = adm_all ? real(1) : real(0);  // adm_q is zero when adm_all is set
     for (int c = 0; c < count; c++) {
         const HitChunk<real> ch = load_uniform(chunks + c);
 #pragma unroll
         for (int k = 0; k < HIT_CHUNK; k++) {
-            real t;
-            const bool inside = axis_hit(ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, t);
-            consider(best, inside, t, ch.r[k].index, adm_q, adm_all, skip, dnorm);
+            if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
+                consider_axis_f32(best, ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, adm_q, adm_bias, skip);
+            } else {
+                real t;
+                const bool inside = axis_hit(ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, t);
+                consider(best, inside, t, ch.r[k].index, adm_q, adm_all, skip, dnorm);
+            }
         }
     }
 }
