@@ -941,19 +941,17 @@ __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real 
     best.e = ok ? index : best.e;
 }
 
-// The float32 form of axis_hit + consider for one record.  The five conditions
-// narrow the execution mask one compare after the other and the two moves then
-// update the running minimum under the narrowed mask: no mask algebra on the
-// scalar unit, which this loop otherwise keeps as busy as the vector unit.
-// `ta` carries the admissibility test as a sign: t * adm_q + bias, bias > 0
-// when every candidate is admissible.
-__device__ __forceinline__ void consider_axis_f32(Nearest<float> &best, const HitRec<float> &r, float inv_dk,
-                                                  float m_lk, float Li, float Di, float Lj, float Dj, float adm_q,
-                                                  float adm_bias, int skip)
+// The float32 form of `consider` for a rectangle: in-plane offsets di, dj
+// against half extents hi, hj.  The five conditions narrow the execution mask
+// one compare after the other and the two moves then update the running
+// minimum under the narrowed mask: no mask algebra on the scalar unit, which
+// this loop otherwise keeps as busy as the vector unit.  `ta` carries the
+// admissibility test as a sign: t * adm_q + bias, bias > 0 when every
+// candidate is admissible.  A line parallel to the plane gives t = inf or NaN,
+// which fails the comparisons.
+__device__ __forceinline__ void consider_f32(Nearest<float> &best, float t, float di, float hi, float dj, float hj,
+                                             float ta, int index, int skip)
 {
-    const float t = r.p0 * inv_dk + m_lk;
-    const float di = (Li + t * Di) - r.ci, dj = (Lj + t * Dj) - r.cj;
-    const float ta = t * adm_q + adm_bias;
     unsigned long long saved;
     asm("s_mov_b64 %[sv], exec\n\t"
         "v_cmpx_le_f32_e64 vcc, |%[di]|, %[hi]\n\t"
@@ -965,9 +963,29 @@ __device__ __forceinline__ void consider_axis_f32(Nearest<float> &best, const Hi
         "v_mov_b32_e32 %[be], %[idx]\n\t"
         "s_mov_b64 exec, %[sv]"
         : [bt] "+v"(best.t), [be] "+v"(best.e), [sv] "=&s"(saved)
-        : [di] "v"(di), [dj] "v"(dj), [hi] "s"(r.hi), [hj] "s"(r.hj), [ta] "v"(ta), [idx] "s"(r.index),
-          [skip] "v"(skip), [t] "v"(t)
+        : [di] "v"(di), [dj] "v"(dj), [hi] "s"(hi), [hj] "s"(hj), [ta] "v"(ta), [idx] "s"(index), [skip] "v"(skip),
+          [t] "v"(t)
         : "vcc");
+}
+
+__device__ __forceinline__ void consider_axis_f32(Nearest<float> &best, const HitRec<float> &r, float inv_dk,
+                                                  float m_lk, float Li, float Di, float Lj, float Dj, float adm_q,
+                                                  float adm_bias, int skip)
+{
+    const float t = r.p0 * inv_dk + m_lk;
+    consider_f32(best, t, (Li + t * Di) - r.ci, r.hi, (Lj + t * Dj) - r.cj, r.hj, t * adm_q + adm_bias, r.index, skip);
+}
+
+__device__ __forceinline__ void consider_rect_f32(Nearest<float> &best, const DevElem<float> &e, int index, float Lx,
+                                                  float Ly, float Lz, float Dx, float Dy, float Dz, float adm_q,
+                                                  float adm_bias, int skip)
+{
+    const float den = Dx * e.nx + Dy * e.ny + Dz * e.nz;
+    const float num = e.d0 - (Lx * e.nx + Ly * e.ny + Lz * e.nz);
+    const float t = num * M<float>::rcp(den);
+    const float Bx = Lx + t * Dx, By = Ly + t * Dy, Bz = Lz + t * Dz;
+    consider_f32(best, t, Bx * e.ax + By * e.ay + Bz * e.az - e.c1, e.h1, Bx * e.bx + By * e.by + Bz * e.bz - e.c2,
+                 e.h2, t * adm_q + adm_bias, index, skip);
 }
 
 // One group of axis-aligned rectangles, one chunk of records per scalar fetch.
@@ -1030,6 +1048,9 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
                 const bool inside = shape_hit(e, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, (p.flags & F_WAS_EL) != 0u,
                                               index == skip, dnorm, t);
                 consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm);
+            } else if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
+                consider_rect_f32(nearest, load_uniform(sc.elems + index), index, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz,
+                                  p.adm_q, adm_all ? real(1) : real(0), skip);
             } else {
                 const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
                 consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);

@@ -1,0 +1,26 @@
+"""Kernel photons/s of the named parity configurations on one GPU, without the
+checker: the quick A/B companion of results_table.py (RTMC_LIBRARY selects the
+build).
+
+usage: python tools/rate.py [photons] [config ...]"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import helpers as H  # noqa: E402
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 50000000
+names = sys.argv[2:] or ["C2", "C2r", "C5", "C7", "C8"]
+out = []
+for name in names:
+    s = H.raytrace_for(name).Scene()
+    m = n // 50 if name in ("C1_open", "C8") else n
+    s.run(min(m, 1000000), seed=3)
+    best = 1e30
+    for rep in range(3):
+        s.run(m, seed=7 + rep)
+        best = min(best, s.last_kernel_ms())
+    out.append("%s %.4g" % (name, m / (best * 1e-3)))
+print(os.environ.get("RTMC_LIBRARY", "default"), "  ".join(out), flush=True)
