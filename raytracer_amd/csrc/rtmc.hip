@@ -634,6 +634,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         img.n_group[group] = (int)(recs.size() / HIT_CHUNK);
         for (size_t c = 0; c < recs.size(); c += HIT_CHUNK) {
             HitChunk<real> ch;
+            memset(&ch, 0, sizeof ch);
             for (int k = 0; k < HIT_CHUNK; k++) ch.r[k] = recs[c + k];
             img.hits.push_back(ch);
         }

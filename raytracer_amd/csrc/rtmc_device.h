@@ -65,11 +65,10 @@ template <typename real>
 struct HitRec {
     real p0, ci, cj, hi, hj;
     int32_t index;  // position in the scene's element list
-    int32_t pad[sizeof(real) == 4 ? 2 : 5];
 };
 
-// The search reads the table two records at a time (one 64-byte scalar load,
-// one wait); every axis group is padded to a multiple of two with records that
+// The search reads the table two records at a time (the twelve words of a
+// float32 chunk come in two scalar loads behind one wait); every axis group is padded to a multiple of two with records that
 // can never be hit (negative half extents).  Four at a time halves the number
 // of waits but keeps 32 SGPRs busy, which the allocator pays for with spills.
 #ifndef RTMC_HIT_CHUNK
