@@ -786,6 +786,22 @@ __device__ __forceinline__ T load_uniform(const T *ptr)
     return u.value;
 }
 
+// The same with the address given as a wave-uniform base and a 32-bit byte
+// offset, which is the form a scalar load takes its address in: a loop over a
+// table then advances and tests one 32-bit register.
+template <typename T>
+__device__ __forceinline__ T load_uniform_at(const T *base, uint32_t byte_offset)
+{
+    static_assert(sizeof(T) % 4 == 0, "record size");
+    typedef const char __attribute__((address_space(4))) *ConstBytes;
+    typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
+    const ConstWords w = (ConstWords)((ConstBytes)(uintptr_t)base + byte_offset);
+    union { T value; uint32_t words[sizeof(T) / 4]; } u;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) u.words[i] = w[i];
+    return u.value;
+}
+
 // ---------------------------------------------------------------------------
 // nearest valid hit
 // ---------------------------------------------------------------------------
@@ -949,11 +965,9 @@ __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real 
 // candidate is admissible.  A line parallel to the plane gives t = inf or NaN,
 // which fails the comparisons.
 __device__ __forceinline__ void consider_f32(Nearest<float> &best, float t, float di, float hi, float dj, float hj,
-                                             float ta, int index, int skip)
+                                             float ta, int index, int skip, unsigned long long saved)
 {
-    unsigned long long saved;
-    asm("s_mov_b64 %[sv], exec\n\t"
-        "v_cmpx_le_f32_e64 vcc, |%[di]|, %[hi]\n\t"
+    asm("v_cmpx_le_f32_e64 vcc, |%[di]|, %[hi]\n\t"
         "v_cmpx_le_f32_e64 vcc, |%[dj]|, %[hj]\n\t"
         "v_cmpx_lt_f32_e32 vcc, 0, %[ta]\n\t"
         "v_cmpx_ne_u32_e32 vcc, %[idx], %[skip]\n\t"
@@ -961,45 +975,48 @@ __device__ __forceinline__ void consider_f32(Nearest<float> &best, float t, floa
         "v_mov_b32_e32 %[bt], %[t]\n\t"
         "v_mov_b32_e32 %[be], %[idx]\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [bt] "+v"(best.t), [be] "+v"(best.e), [sv] "=&s"(saved)
+        : [bt] "+v"(best.t), [be] "+v"(best.e)
         : [di] "v"(di), [dj] "v"(dj), [hi] "s"(hi), [hj] "s"(hj), [ta] "v"(ta), [idx] "s"(index), [skip] "v"(skip),
-          [t] "v"(t)
+          [t] "v"(t), [sv] "s"(saved)
         : "vcc");
 }
 
 __device__ __forceinline__ void consider_axis_f32(Nearest<float> &best, const HitRec<float> &r, float inv_dk,
                                                   float m_lk, float Li, float Di, float Lj, float Dj, float adm_q,
-                                                  float adm_bias, int skip)
+                                                  float adm_bias, int skip, unsigned long long saved)
 {
     const float t = r.p0 * inv_dk + m_lk;
-    consider_f32(best, t, (Li + t * Di) - r.ci, r.hi, (Lj + t * Dj) - r.cj, r.hj, t * adm_q + adm_bias, r.index, skip);
+    consider_f32(best, t, (Li + t * Di) - r.ci, r.hi, (Lj + t * Dj) - r.cj, r.hj, t * adm_q + adm_bias, r.index, skip,
+                 saved);
 }
 
 __device__ __forceinline__ void consider_rect_f32(Nearest<float> &best, const DevElem<float> &e, int index, float Lx,
                                                   float Ly, float Lz, float Dx, float Dy, float Dz, float adm_q,
-                                                  float adm_bias, int skip)
+                                                  float adm_bias, int skip, unsigned long long saved)
 {
     const float den = Dx * e.nx + Dy * e.ny + Dz * e.nz;
     const float num = e.d0 - (Lx * e.nx + Ly * e.ny + Lz * e.nz);
     const float t = num * M<float>::rcp(den);
     const float Bx = Lx + t * Dx, By = Ly + t * Dy, Bz = Lz + t * Dz;
     consider_f32(best, t, Bx * e.ax + By * e.ay + Bz * e.az - e.c1, e.h1, Bx * e.bx + By * e.by + Bz * e.bz - e.c2,
-                 e.h2, t * adm_q + adm_bias, index, skip);
+                 e.h2, t * adm_q + adm_bias, index, skip, saved);
 }
 
 // One group of axis-aligned rectangles, one chunk of records per scalar fetch.
 template <typename real>
-__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *chunks, int count, real inv_dk, real m_lk,
-                                                real Li, real Di, real Lj, real Dj, real adm_q, bool adm_all,
-                                                int skip, real dnorm, Nearest<real> &best)
+__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *table, uint32_t &offset, int count,
+                                                real inv_dk, real m_lk, real Li, real Di, real Lj, real Dj,
+                                                real adm_q, bool adm_all, int skip, real dnorm,
+                                                unsigned long long lanes, Nearest<real> &best)
 {
     [[maybe_unused]] const real adm_bias = adm_all ? real(1) : real(0);  // adm_q is zero when adm_all is set
-    for (int c = 0; c < count; c++) {
-        const HitChunk<real> ch = load_uniform(chunks + c);
+    const uint32_t end = offset + (uint32_t)count * (uint32_t)sizeof(HitChunk<real>);
+    for (; offset != end; offset += (uint32_t)sizeof(HitChunk<real>)) {
+        const HitChunk<real> ch = load_uniform_at(table, offset);
 #pragma unroll
         for (int k = 0; k < HIT_CHUNK; k++) {
             if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
-                consider_axis_f32(best, ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, adm_q, adm_bias, skip);
+                consider_axis_f32(best, ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, adm_q, adm_bias, skip, lanes);
             } else {
                 real t;
                 const bool inside = axis_hit(ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, t);
@@ -1027,15 +1044,19 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
     Nearest<real> nearest;
     nearest.t = M<real>::inf();
     nearest.e = -1;
-    const HitChunk<real> *chunks = sc.hits;
-    scan_axis_group(chunks, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm, nearest);
-    chunks += sc.n_group[0];
-    scan_axis_group(chunks, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm, nearest);
-    chunks += sc.n_group[1];
-    scan_axis_group(chunks, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm, nearest);
-    chunks += sc.n_group[2];
-    for (int c = 0; c < sc.n_group[3]; c++) {
-        const HitChunk<real> ch = load_uniform(chunks + c);
+    // the execution mask of the whole (wave-uniform) search; the float32 tests
+    // narrow it per record and return to this value
+    const unsigned long long lanes = __builtin_amdgcn_read_exec();
+    uint32_t offset = 0;  // bytes into the hit table
+    scan_axis_group(sc.hits, offset, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm,
+                    lanes, nearest);
+    scan_axis_group(sc.hits, offset, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm,
+                    lanes, nearest);
+    scan_axis_group(sc.hits, offset, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm,
+                    lanes, nearest);
+    const uint32_t end = offset + (uint32_t)sc.n_group[3] * (uint32_t)sizeof(HitChunk<real>);
+    for (; offset != end; offset += (uint32_t)sizeof(HitChunk<real>)) {
+        const HitChunk<real> ch = load_uniform_at(sc.hits, offset);
 #pragma unroll
         for (int k = 0; k < HIT_CHUNK; k++) {
             const int index = ch.r[k].index;
@@ -1049,7 +1070,7 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
                 consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm);
             } else if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
                 consider_rect_f32(nearest, load_uniform(sc.elems + index), index, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz,
-                                  p.adm_q, adm_all ? real(1) : real(0), skip);
+                                  p.adm_q, adm_all ? real(1) : real(0), skip, lanes);
             } else {
                 const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
                 consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
