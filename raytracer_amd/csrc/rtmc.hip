@@ -87,7 +87,11 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // takes part in the next loop iteration.  Launch and re-emission share one
 // Philox event and one pass through the direction / polarisation samplers.
 // The grid is sized to the machine, not to n.
-enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3 };
+// NEED_RETIRE: the photon has ended but its tallies are still to be written;
+// NEED_EMIT: absorbed, still at the point where its last search began.  Both are
+// dealt with at the head of the renew block, for the lanes of all iterations
+// since the last pass at once.
+enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3, NEED_RETIRE = 4 };
 // When to run the renew block.  It costs R (about half a loop iteration)
 // whatever the number of lanes in it, while every lane that waits for it wastes
 // 1/64 of an iteration S per iteration.  Running it every P iterations costs
@@ -151,7 +155,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     for (;;) {
         // (Single exit and no `continue`: with two back edges the compiler copied the
         // whole photon record to other registers and back on every iteration.)
-        const unsigned long long want = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
+        const unsigned long long want = __ballot(need == NEED_LAUNCH || need == NEED_EMIT || need == NEED_RETIRE);
         const unsigned long long stepping = __ballot(need == NEED_NONE);
         if ((want | stepping) == 0ull) break;  // every lane is switched off
         idle_debt += __popcll(want);
@@ -159,12 +163,18 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             idle_debt = 0;
             SECTION_BEGIN();
 #ifdef RTMC_PROFILE_SECTIONS
-            const unsigned long long renew_mask = __ballot(need == NEED_LAUNCH || need == NEED_EMIT);
+            const unsigned long long renew_mask = __ballot(need == NEED_LAUNCH || need == NEED_EMIT || need == NEED_RETIRE);
 #endif
             // (a) absorbed photons: donor/acceptor coin and pathway (PhotonObject.py:244,
             //     MonteCarloFRET.py:63-193); one event, a back transfer opens another
             bool emitting = false;
+            if (need == NEED_RETIRE) {
+                if (p.status == RTMC_ST_DUMPED) finish_dumped(hot, lds, p, g, tally);
+                count_fate(p, tally);
+                need = NEED_LAUNCH;
+            }
             if (need == NEED_EMIT) {
+                finish_absorbed_move(p, tally);
                 const DevMat<real> &m = lds.mats[p.mat];
                 const DevAbs<real> &a = lds.abs[m.abs_slot * hot.n_wid + p.wid];
                 const bool in_donor = absorbed_by_donor<ALIGNED>(m, a, p, g);
@@ -233,13 +243,8 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
         const unsigned long long step_mask = __ballot(need == NEED_NONE);
 #endif
         if (need == NEED_NONE) {
-            const StepResult r = photon_step<FEATURES>(hot, lds, p, g, tally);
-            if (r == STEP_ENDED) {
-                count_fate(p, tally);
-                need = NEED_LAUNCH;
-            } else if (r == STEP_ABSORBED) {
-                need = NEED_EMIT;
-            }
+            const StepResult r = photon_step<FEATURES, true>(hot, lds, p, g, tally);
+            need = r == STEP_ENDED ? NEED_RETIRE : (r == STEP_ABSORBED ? NEED_EMIT : NEED_NONE);
         }
         SECTION_END(cyc_step, n_step, lanes_step, step_mask);
     }
@@ -343,7 +348,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
                    p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
     for (uint32_t it = 0; it < n_steps && alive; it++) {
-        StepResult r = photon_step<FEAT_ALIGNED | FEAT_SHAPES>(hot, lds, p, g, tally);
+        StepResult r = photon_step<FEAT_ALIGNED | FEAT_SHAPES, false>(hot, lds, p, g, tally);
         if (r == STEP_ABSORBED) {
             emit_in_reference_order(hot, lds, p, g);
             r = finish_absorbed_iteration(hot, p);

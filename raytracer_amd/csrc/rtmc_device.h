@@ -1135,11 +1135,53 @@ struct NoTally {
 enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
 
 
+// PhotonObject.py:216-233: an absorbed photon moves the rest of its free path
+// towards the candidate point of its last search (p.best_t, p.hitd); with no
+// candidate the reference aims at PointCy = (0,0,0).
+template <typename real, typename Tally>
+__device__ __forceinline__ void finish_absorbed_move(Photon<real> &p, Tally &tally)
+{
+    const bool stale = !(p.hitd < M<real>::inf());
+    p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+    real ux, uy, uz;
+    if (!stale) {
+        const real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+        real s = (p.best_t < real(0) ? real(-1) : real(1)) * M<real>::rcp(dnorm);
+        ux = p.Dx * s; uy = p.Dy * s; uz = p.Dz * s;
+    } else {
+        ux = -p.Lx; uy = -p.Ly; uz = -p.Lz;
+        normalize3(ux, uy, uz);
+    }
+    p.Lx += ux * p.dist; p.Ly += uy * p.dist; p.Lz += uz * p.dist;
+    set_admissibility_forward(p);
+    tally.scalar(ACC_ABSORPTIONS);
+}
+
+// Elements.py:152-165: the tallies of the detector the photon ended on
+// (p.last_el); the efficiency draw is word 0 of the iteration's variates.
+template <typename real, bool TAPE, typename Tally>
+__device__ __forceinline__ void finish_dumped(const HotScene<real> &sc, const Lds<real> &lds, const Photon<real> &p,
+                                              Rng<real, TAPE> &g, Tally &tally)
+{
+    const int info = lds.elems[p.last_el].info;
+    bool counted = true;
+    const int eqe = (info & 0xFF) - 1;
+    if (eqe >= 0) counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
+    tally.dump(p.last_el, info >> 8, p.wid, p.wid0, counted);
+}
+
 // One iteration of the loop body, RayTrace.py:178-195, up to the point where an
 // absorbed photon needs its pathway drawn: the caller does that
 // (emit_in_reference_order / the renew block of the trace kernel) and then
 // calls finish_absorbed_iteration.
-template <int FEATURES, typename real, bool TAPE, typename Tally>
+//
+// DEFER_ENDINGS: what an absorbed or detected photon still has to do after the
+// iteration has decided its fate (the move to the absorption point, the
+// detector tallies) is left to finish_absorbed_move / finish_dumped.  Such a
+// lane takes no further step before the caller has dealt with it, and a caller
+// that deals with the lanes of several iterations at once (the renew block of
+// the trace kernel) runs that code once for all of them.
+template <int FEATURES, bool DEFER_ENDINGS, typename real, bool TAPE, typename Tally>
 __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, const Lds<real> &lds,
                                                   Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
 {
@@ -1176,20 +1218,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
         } else {
             p.flags = (p.flags | F_ABS_ONCE) & ~F_WAS_EL;
             p.status = RTMC_ST_ABSORBED;
-            p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
-            // move the rest of the free path towards the candidate point; with
-            // no candidate the reference aims at PointCy = (0,0,0)
-            real ux, uy, uz;
-            if (!stale) {
-                real s = (best_t < real(0) ? real(-1) : real(1)) * M<real>::rcp(dnorm);
-                ux = p.Dx * s; uy = p.Dy * s; uz = p.Dz * s;
-            } else {
-                ux = -p.Lx; uy = -p.Ly; uz = -p.Lz;
-                normalize3(ux, uy, uz);
-            }
-            p.Lx += ux * p.dist; p.Ly += uy * p.dist; p.Lz += uz * p.dist;
-            set_admissibility_forward(p);
-            tally.scalar(ACC_ABSORPTIONS);
+            if (!DEFER_ENDINGS) finish_absorbed_move(p, tally);
             return STEP_ABSORBED;
         }
     } else {
@@ -1230,12 +1259,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
         }
         if (type == RTMC_TYPE_DUMP) {  // Elements.py:152-169
             p.status = RTMC_ST_DUMPED;
-            bool counted = true;
-            const int eqe = (info & 0xFF) - 1;
-            if (eqe >= 0) {
-                counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
-            }
-            tally.dump(el_idx, info >> 8, p.wid, p.wid0, counted);
+            if (!DEFER_ENDINGS) finish_dumped(sc, lds, p, g, tally);
             p.flags |= F_WAS_EL;
             p.iter++;
             return STEP_ENDED;
