@@ -467,7 +467,8 @@ __device__ __forceinline__ void set_admissibility(Photon<real> &p, int type, int
     const bool want_same = type == RTMC_TYPE_MIRROR ? true
                          : (type == RTMC_TYPE_INTERFACE ? (p.flags & F_REFLECTED) != 0u : false);
     set_flag(p, F_ADM_ALL, (side == 0) & !want_same);
-    p.adm_q = side == 0 ? real(0) : (want_same ? nd * real(side) : -nd * real(side));
+    const real q = nd * real(side);  // zero when the old point has no side
+    p.adm_q = want_same ? q : -q;
 }
 
 // A photon that does not come from an element (launch, re-emission) accepts
@@ -1312,7 +1313,13 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
                      kz = sgn * (p.Dx * ny - p.Dy * nx);
                 real k2 = kx * kx + ky * ky + kz * kz;
                 real R;
-                if (k2 != real(0)) {
+                if (!M<real>::has_self_hit_eps) {
+                    // exactly normal incidence (k = 0): both coefficients equal ((n1 - n2)/(n1 + n2))^2 up to
+                    // rounding, so float32 takes R_par there and needs no branch
+                    real dp = (p.Ex * kx + p.Ey * ky + p.Ez * kz);
+                    real dp2 = k2 != real(0) ? dp * dp * M<real>::rcp(k2) : real(0);
+                    R = (real(1) - dp2) * R_par + dp2 * R_perp;
+                } else if (k2 != real(0)) {
                     real dp = (p.Ex * kx + p.Ey * ky + p.Ez * kz);
                     real dp2 = dp * dp * M<real>::rcp(k2);
                     R = (real(1) - dp2) * R_par + dp2 * R_perp;
@@ -1373,8 +1380,11 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             const real sy = reflect ? k * ny : oDy * ia + p.Dy * ib;
             const real sz = reflect ? k * nz : oDz * ia + p.Dz * ib;
             const real h = real(0.5) * (sx * sx + sy * sy + sz * sz);
-            if (h > real(0)) {
-                const real se = (sx * p.Ex + sy * p.Ey + sz * p.Ez) * M<real>::rcp(h);
+            // h = 0 (a = -b: no rotation) leaves s = 0 and E + 2 b (a.E) with a.E = 0 up to rounding, so
+            // float32 guards the division only; float64 skips the update like the reference
+            if (!M<real>::has_self_hit_eps || h > real(0)) {
+                const real se = (sx * p.Ex + sy * p.Ey + sz * p.Ez) *
+                                M<real>::rcp(M<real>::has_self_hit_eps || h > real(1e-30) ? h : real(1e-30));
                 const real ae = real(2) * (oDx * p.Ex + oDy * p.Ey + oDz * p.Ez) * (ia * ib);
                 real ex = p.Ex - sx * se + p.Dx * ae;
                 real ey = p.Ey - sy * se + p.Dy * ae;
