@@ -24,10 +24,12 @@ for name in ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C
     s = rt.Scene()
     n = int(n_default if name not in ("C1_open", "C8") else n_default / 50)
     s.run(min(n, 1000000), seed=3)                      # warm-up, scene upload
-    t0 = time.perf_counter()
-    t = s.run(n, seed=7)
-    wall = time.perf_counter() - t0
-    ms = s.last_kernel_ms()
+    ms, wall = 1e30, 1e30
+    for rep in range(3):                                # same seed, same tallies: best of three timings
+        t0 = time.perf_counter()
+        t = s.run(n, seed=7)
+        wall = min(wall, time.perf_counter() - t0)
+        ms = min(ms, s.last_kernel_ms())
     n_el = s.n_elements
     edges = [i for i, oe in enumerate(rt.OpticalElements)
              if oe.Type.kind == "Dump" and i < n_el - 6] if name != "C1_open" else [2, 3, 4, 5]
