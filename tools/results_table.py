@@ -1,5 +1,5 @@
 """Throughput, path statistics and optical-efficiency deltas for every parity
-configuration, one GPU; prints a markdown table (BASELINE.md section 4).
+configuration, one GPU; prints a markdown table.
 
 usage: python tools/results_table.py [photons_per_config]"""
 import json
