@@ -422,6 +422,39 @@ def test_reference_demo_scene(oracle_mod):
     s.close()
 
 
+def test_full_size_launch_properties(scenes):
+    """The bench workload at its full size (C2, 2.5e8 photons in one call),
+    checked through what must hold at any size: every photon has exactly one
+    fate, per-detector spectra add up to the counters, the energy of a
+    red-shifted photon is below one source quantum, the id range can be cut
+    anywhere without changing one integer, and the edge efficiency agrees with
+    the reference's own runs."""
+    rt, s = scenes("C2")
+    n, cut = 250000000, 100000003
+    whole = s.run(n, seed=1)
+    assert whole["n_photons"] == n
+    assert whole["n_dumped"] + whole["n_internal_converted"] + whole["n_capped"] + whole["n_lost"] == n
+    assert int(whole["counter"].sum()) == whole["n_dumped"]          # no efficiency table in this scene
+    assert np.array_equal(whole["spectrum"].sum(axis=1), whole["counter"])
+    assert np.all(whole["energy_fx"] <= whole["counter"] * 2 ** 24)
+    assert n <= whole["n_steps"] <= 10001 * n and whole["n_absorbed_once"] <= n
+    assert whole["n_absorptions"] >= whole["n_absorbed_once"]
+    block = sc.new_tallies(s.n_elements)
+    s.run(cut, seed=1, first_photon=0, tallies=block)
+    s.run(n - cut, seed=1, first_photon=cut, tallies=block)
+    parts = sc.tallies_to_dict(*block)
+    for key in ("counter", "spectral", "bounce", "energy_fx", "spectrum"):
+        assert np.array_equal(whole[key], parts[key]), key
+    for key in _abi.TALLY_SCALARS:
+        assert whole[key] == parts[key], key
+    ref = H.ref_tallies("C2")
+    n_ref = sum(r["n"] for r in ref)
+    edges = [i for i, oe in enumerate(rt.OpticalElements) if oe.Type.kind == "Dump" and i < s.n_elements - 6]
+    eta = float(whole["counter"][edges].sum()) / n
+    eta_ref = float(np.sum([r["counter"] for r in ref], axis=0)[edges].sum()) / n_ref
+    assert abs(eta - eta_ref) <= 3 * (eta * (1 - eta) / n_ref) ** 0.5, (eta, eta_ref)
+
+
 def test_long_runs_are_split_into_launches(scenes, monkeypatch):
     """rtmc_run cuts an id range into several launches when it is very long;
     with the limit lowered for the test the result is the single-launch one."""
