@@ -149,6 +149,12 @@ typedef struct rtmc_source {
     int32_t start_material;
     int32_t respect_polarization;
     double scale_factor;
+    double area[2];          /* full widths along x and y of a launch
+                                rectangle centred on `location` (0, 0: point
+                                source).  The reference keeps this launch area
+                                as commented-out lines with fixed sizes
+                                (PhotonObject.py:74-84): two uniforms drawn
+                                after the direction, x then y              */
 } rtmc_source;
 
 typedef struct rtmc_scene_desc {

@@ -543,6 +543,11 @@ static void launch_photon(const orc_scene *s, ph_t *p, rng_t *g)
             p->D[j] = fma(d[2], src->frame[6 + j], fma(d[1], src->frame[3 + j], d[0] * src->frame[j]));
     } else
         memcpy(p->D, src->direction, sizeof p->D);
+    const int has_area = src->area[0] != 0.0 || src->area[1] != 0.0;
+    if (has_area && g->tape_mode) { /* PhotonObject.py:76,84 (commented out there): rand() for x, then for y */
+        p->L[0] += (tape_next(g, DRAW_UNIFORM) - 0.5) * src->area[0];
+        p->L[1] += (tape_next(g, DRAW_UNIFORM) - 0.5) * src->area[1];
+    }
     double n = norm3(p->D);
     p->D[0] /= n; p->D[1] /= n; p->D[2] /= n;
     if (src->wavelength_mode == 1)
@@ -552,6 +557,11 @@ static void launch_photon(const orc_scene *s, ph_t *p, rng_t *g)
     p->mat = src->start_material;
     if (g->tape_mode) polarization_random(p, g, p->D);
     else perpendicular(p->D, u24(g->w[2]), p->E);
+    if (has_area && !g->tape_mode) { /* philox: a block of its own, words 0, 1 */
+        rng_block(g, 0, BLK_LAUNCH + 1u);
+        p->L[0] += (u24(g->w[0]) - 0.5) * src->area[0];
+        p->L[1] += (u24(g->w[1]) - 0.5) * src->area[1];
+    }
     p->wl0 = p->wl;
     p->reflected = 0;
     if (s->n_el > 0) {

@@ -24,7 +24,7 @@ STRICT = "Directional Strict"
 class Photon:
     def __init__(self, Location=[0, 0, 0], EmissionMode=ISOTROPIC, EmissionDirection=[0, 0, 0],
                  EmissionWavelengthType=SUN, StartingWavelength=450.0, StartingMaterial=None,
-                 RespectPolarization=True, StartingLocation=[0, 0, 0], ScaleFactor=1.0):
+                 RespectPolarization=True, StartingLocation=[0, 0, 0], ScaleFactor=1.0, LaunchArea=None):
         self.Location = Location
         self.EmissionMode = EmissionMode
         self.EmissionDirection = EmissionDirection
@@ -34,6 +34,10 @@ class Photon:
         self.RespectPolarization = RespectPolarization
         self.StartingLocation = StartingLocation
         self.ScaleFactor = ScaleFactor
+        # (width along x, width along y) of a launch rectangle centred on
+        # StartingLocation; None: point source.  The reference has this as
+        # commented-out lines with fixed sizes (PhotonObject.py:74-84).
+        self.LaunchArea = LaunchArea
         # state attributes of the reference object (PhotonObject.py:21-37)
         self.PointCy = [0, 0, 0]
         self.OperationPlane = [[0, 0, 0], [0, 0, 0]]

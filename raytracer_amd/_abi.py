@@ -67,7 +67,7 @@ class Source(C.Structure):
                 ("location", c_double3), ("direction", c_double3), ("frame", c_double9),
                 ("wavelength", C.c_double), ("spectrum", Table),
                 ("start_material", C.c_int32), ("respect_polarization", C.c_int32),
-                ("scale_factor", C.c_double)]
+                ("scale_factor", C.c_double), ("area", C.c_double * 2)]
 
 
 class SceneDesc(C.Structure):

@@ -770,6 +770,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     o.inv_scale = (real)(1.0 / s.scale_factor);
     o.dir_mode = s.direction_mode; o.wl_mode = s.wavelength_mode; o.start_mat = s.start_material;
     o.wid_fixed = 0;
+    o.has_area = (s.area[0] != 0.0 || s.area[1] != 0.0) ? 1 : 0;
+    o.area[0] = (real)s.area[0]; o.area[1] = (real)s.area[1];
     if (src_cdf >= 0) {
         o.cdf_off = cdf_off[src_cdf]; o.cdf_len = (int)cdfs[src_cdf].size();
         o.guide_off = src_cdf * (GUIDE_BUCKETS + 1);
@@ -808,6 +810,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     const rtmc_source &src = d->source;
     if (src.start_material < 0 || src.start_material >= d->n_materials) return fail(RTMC_EINVAL, "start material out of range");
     if (!(src.scale_factor > 0)) return fail(RTMC_EINVAL, "scale_factor must be positive");
+    if (!(src.area[0] >= 0 && src.area[1] >= 0 && std::isfinite(src.area[0]) && std::isfinite(src.area[1])))
+        return fail(RTMC_EINVAL, "source area widths must be finite and not negative");
     if (src.direction_mode != 0 && src.direction_mode != 1) return fail(RTMC_EINVAL, "unknown direction mode");
     bool has_shapes = false;
     for (int i = 0; i < d->n_elements; i++) {

@@ -123,7 +123,9 @@ struct DevSource {
     real inv_scale;  // 1 / ScaleFactor
     int32_t dir_mode, wl_mode, start_mat, wid_fixed;
     int32_t cdf_off, cdf_len;  // source spectrum thresholds; wavelength id = row
-    int32_t guide_off, pad;    // its guide table
+    int32_t guide_off;         // its guide table
+    int32_t has_area;          // launch positions spread over a rectangle
+    real area[2];              // its full widths along x and y
 };
 
 // Offsets (in bytes) into the LDS image.
@@ -272,6 +274,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 // In tape mode the values are read sequentially in the order the reference
 // draws them.
 enum : uint32_t { BLK_STEP = 0u, BLK_EMIT = 0x80000000u, BLK_LAUNCH = 0xC0000000u };
+// BLK_LAUNCH + 1: launch position inside the source's rectangle [x, y] (extended sources only)
 template <typename real, bool TAPE>
 struct Rng;
 
@@ -546,6 +549,10 @@ __device__ __forceinline__ void launch_in_reference_order(SceneArg<real> sc, con
     } else {
         p.Dx = s.dir[0]; p.Dy = s.dir[1]; p.Dz = s.dir[2];
     }
+    if (s.has_area) {  // PhotonObject.py:76,84 (commented out in the reference): rand() for x, then for y
+        p.Lx += (g.uniform(0) - real(0.5)) * s.area[0];
+        p.Ly += (g.uniform(0) - real(0.5)) * s.area[1];
+    }
     p.wid = s.wl_mode == 1 ? cdf_pick(lds.cdf + s.cdf_off, s.cdf_len, g.u32(0)) : s.wid_fixed;
     random_polarization(p, g);
     init_photon_common(sc, p);
@@ -733,6 +740,11 @@ __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<r
     if (launching) {
         p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
         p.wid = s.wl_mode == 1 ? cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3)) : s.wid_fixed;
+        if (s.has_area) {  // a block of its own: words 0, 1 = position along x, y
+            g.block(0u, BLK_LAUNCH + 1u);
+            p.Lx += (g.uniform(0) - real(0.5)) * s.area[0];
+            p.Ly += (g.uniform(1) - real(0.5)) * s.area[1];
+        }
         init_photon_common(sc, p);
     }
     p.dist = dist;

@@ -181,6 +181,8 @@ def pack_source(photon, mats, pool):
     s.start_material = next(i for i, m in enumerate(mats) if m is photon.StartingMaterial)
     s.respect_polarization = int(bool(photon.RespectPolarization))
     s.scale_factor = float(photon.ScaleFactor)
+    area = getattr(photon, "LaunchArea", None) or (0.0, 0.0)
+    s.area = (C.c_double * 2)(float(area[0]), float(area[1]))
     return s
 
 

@@ -455,6 +455,30 @@ def test_full_size_launch_properties(scenes):
     assert abs(eta - eta_ref) <= 3 * (eta * (1 - eta) / n_ref) ** 0.5, (eta, eta_ref)
 
 
+def test_extended_source(oracle_mod):
+    """Launch points spread over a rectangle (the reference keeps that as
+    commented-out lines, PhotonObject.py:74-84; nothing of the reference pins
+    it): tape-driven launches land where the law says in float64 and float32,
+    the float64 kernels follow the checker photon for photon and float32 follows
+    float64."""
+    from test_oracle_golden import extended_source_case
+    rt, tape, off, expect = extended_source_case()
+    s = rt.Scene()
+    for precision, tol in ((_abi.F64, 1e-15), (_abi.F32, 5e-7)):
+        batch = sc.new_photon_batch(expect.shape[1])
+        s.step_tape(batch, tape, off, 1, launch=True, precision=precision)
+        assert np.allclose(batch["old_point"], expect, rtol=0, atol=tol), precision
+        assert np.all(batch["iterations"] == 1)
+    n = 200000
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=12, threads=8)
+    g64 = s.run(n, seed=12, precision=_abi.F64)
+    g32 = s.run(n, seed=12)
+    for a, b, slack in ((g64, cpu, 8), (g32, g64, 100)):
+        moved = sum(int(np.abs(a[k].astype(np.int64) - b[k].astype(np.int64)).sum()) for k in ("counter", "spectral"))
+        assert a["n_photons"] == n and moved <= slack, moved
+    s.close()
+
+
 def test_long_runs_are_split_into_launches(scenes, monkeypatch):
     """rtmc_run cuts an id range into several launches when it is very long;
     with the limit lowered for the test the result is the single-launch one."""

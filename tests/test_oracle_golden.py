@@ -226,3 +226,43 @@ def test_crossing_operation_matches_reference_rows(oracle_mod, name):
                 checked += 1
         o.step_tape(batch, g["tape"], g["tape_off"], 1, launch=False)
     assert checked > 300
+
+
+def extended_source_case(n=64, area=(4.0, 3.0), seed=11):
+    """C2 with its launch point spread over a rectangle, a tape that launches
+    `n` photons and takes them through one iteration, and the launch points
+    the tape implies.  Launch draws: rand() for x, rand() for y
+    (PhotonObject.py:76,84, commented out in the reference), then the three
+    normals of the polarisation; the iteration at the slab's top face then
+    takes a Fresnel uniform and a free path."""
+    rt = H.raytrace_for("C2")
+    rt.Photon.LaunchArea = area
+    rt.CreateOpticalElementList()
+    rng = np.random.RandomState(seed)
+    per = 12
+    tape = rng.rand(n, per)
+    tape[:, 2:5] = rng.randn(n, 3)
+    off = np.arange(n + 1, dtype=np.uint64) * per
+    start = np.asarray(rt.Photon.StartingLocation, dtype=np.float64)
+    expect = np.stack([start[0] + (tape[:, 0] - 0.5) * area[0], start[1] + (tape[:, 1] - 0.5) * area[1],
+                       np.full(n, start[2])])
+    return rt, tape.reshape(-1), off, expect
+
+
+def test_extended_source_launch_points(oracle_mod):
+    """No vector of the reference pins this (the lines are commented out
+    there): the test states the law -- uniform over the rectangle centred on
+    StartingLocation, x drawn before y -- and checks the restatement
+    against it, then that a Philox run still accounts for every photon."""
+    from raytracer_amd import scene as sc
+    rt, tape, off, expect = extended_source_case()
+    o = oracle_mod.OracleScene.from_raytrace(rt)
+    batch = sc.new_photon_batch(expect.shape[1])
+    o.step_tape(batch, tape, off, 1, launch=True)
+    assert np.allclose(batch["old_point"], expect, rtol=0, atol=1e-15)
+    assert np.all(batch["iterations"] == 1)
+    n = 20000
+    t = o.run_threads(n, seed=3, threads=4)
+    assert t["n_dumped"] + t["n_internal_converted"] + t["n_capped"] + t["n_lost"] == n
+    point = oracle_mod.OracleScene.from_raytrace(H.raytrace_for("C2")).run_threads(n, seed=3, threads=4)
+    assert not np.array_equal(t["counter"], point["counter"])
