@@ -233,7 +233,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 if (special)
                     renew_emit_aligned(hot, lds, lds.mats[p.mat], p, g, emit_iter);
                 else
-                    renew_photon<ALIGNED>(sc, hot, lds, p, g, launching);
+                    renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0>(sc, hot, lds, p, g, launching);
                 need = NEED_NONE;
             }
             SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);
@@ -517,7 +517,11 @@ struct rtmc_scene {
     int n_el = 0, n_mat = 0, n_eqe = 0, max_iter = 0;
     bool has_aligned = false;       // some medium has aligned acceptor dyes: the kernels with that code are used
     bool has_shapes = false;        // some element is not a rectangle, or is a lens
-    int features() const { return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0); }
+    bool has_area = false;          // the source spreads its launch points: the kernel with every feature is used
+    int features() const
+    {
+        return has_area ? (FEAT_ALIGNED | FEAT_SHAPES | FEAT_AREA) : (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0);
+    }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
@@ -896,6 +900,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     s->n_el = d->n_elements; s->n_mat = d->n_materials; s->n_eqe = d->n_tables; s->max_iter = d->max_iterations;
     s->has_aligned = has_aligned;
     s->has_shapes = has_shapes;
+    s->has_area = src.area[0] != 0.0 || src.area[1] != 0.0;
     s->elements.assign(d->elements, d->elements + d->n_elements);
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
@@ -984,7 +989,8 @@ static const void *trace_function(int features)
     case 0: return (const void *)trace_kernel<real, 0>;
     case 1: return (const void *)trace_kernel<real, 1>;
     case 2: return (const void *)trace_kernel<real, 2>;
-    default: return (const void *)trace_kernel<real, 3>;
+    case 3: return (const void *)trace_kernel<real, 3>;
+    default: return (const void *)trace_kernel<real, FEAT_ALIGNED | FEAT_SHAPES | FEAT_AREA>;
     }
 }
 

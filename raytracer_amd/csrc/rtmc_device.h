@@ -184,7 +184,10 @@ struct HotScene {
 
 // Code a scene may need beyond rectangles with isotropic dyes; kernels are
 // instantiated per combination so that the common case carries none of it.
-enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2 };
+// FEAT_AREA (launch points spread over a rectangle) is only instantiated together
+// with the other two: such a source is rare, and a wave-uniform branch in the
+// lean kernels would still cost them the scalar registers of a third Philox block.
+enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4 };
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -721,7 +724,7 @@ __device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_
 // words 0,1 direction, 2 polarisation angle, 3 free path.
 // Launch or re-emission of the lanes of a wave in one pass: the direction and
 // polarisation samplers are run once for both kinds of lane.
-template <bool ALIGNED, typename real>
+template <bool ALIGNED, bool AREA, typename real>
 __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<real> &hot, const Lds<real> &lds,
                                              Photon<real> &p, Rng<real, false> &g, bool launching)
 {
@@ -740,7 +743,7 @@ __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<r
     if (launching) {
         p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
         p.wid = s.wl_mode == 1 ? cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3)) : s.wid_fixed;
-        if (s.has_area) {  // a block of its own: words 0, 1 = position along x, y
+        if (AREA && s.has_area) {  // a block of its own: words 0, 1 = position along x, y
             g.block(0u, BLK_LAUNCH + 1u);
             p.Lx += (g.uniform(0) - real(0.5)) * s.area[0];
             p.Ly += (g.uniform(1) - real(0.5)) * s.area[1];
