@@ -125,7 +125,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     Lds<real> lds = stage_lds(sc, smem, true);
     const HotScene<real> hot = hot_scene(sc);
 
-    LdsTally<real> tally;
+    LdsTally<real, (FEATURES & FEAT_SPECTRA) != 0> tally;
     tally.acc = lds.acc; tally.hist = lds.hist; tally.fx = lds.fx; tally.bin = lds.bin; tally.wl = sc.wl;
     tally.n_el = sc.n_el; tally.n_bins = (int)sc.lay.n_bins;
     tally.fixed_source = sc.src.wl_mode == 0;
@@ -169,7 +169,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             //     MonteCarloFRET.py:63-193); one event, a back transfer opens another
             bool emitting = false;
             if (need == NEED_RETIRE) {
-                if (p.status == RTMC_ST_DUMPED) finish_dumped(hot, lds, p, g, tally);
+                if (p.status == RTMC_ST_DUMPED) finish_dumped<(FEATURES & FEAT_SPECTRA) != 0>(hot, lds, p, g, tally);
                 count_fate(p, tally);
                 need = NEED_LAUNCH;
             }
@@ -233,7 +233,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 if (special)
                     renew_emit_aligned(hot, lds, lds.mats[p.mat], p, g, emit_iter);
                 else
-                    renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0>(sc, hot, lds, p, g, launching);
+                    renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0, (FEATURES & FEAT_SPECTRA) != 0>(sc, hot, lds, p, g, launching);
                 need = NEED_NONE;
             }
             SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);
@@ -335,7 +335,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     }
     if (cross_el) {  // rtmc_op_crossing: the search only
         real dnorm;
-        const Nearest<real> nr = nearest_valid_hit<FEAT_ALIGNED | FEAT_SHAPES>(hot, p, dnorm);
+        const Nearest<real> nr = nearest_valid_hit<FEAT_ALL>(hot, p, dnorm);
         const bool none = nr.e < 0;
         cross_el[k] = nr.e;
         cross_dist[k] = none ? __builtin_huge_val() : (double)(M<real>::abs(nr.t) * dnorm);
@@ -348,7 +348,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     bool alive = !(p.status == RTMC_ST_INTERNAL_CONVERTED || p.status == RTMC_ST_DUMPED ||
                    p.status == RTMC_ST_LOST || p.iter >= sc.max_iter);
     for (uint32_t it = 0; it < n_steps && alive; it++) {
-        StepResult r = photon_step<FEAT_ALIGNED | FEAT_SHAPES, false>(hot, lds, p, g, tally);
+        StepResult r = photon_step<FEAT_ALL, false>(hot, lds, p, g, tally);
         if (r == STEP_ABSORBED) {
             emit_in_reference_order(hot, lds, p, g);
             r = finish_absorbed_iteration(hot, p);
@@ -518,9 +518,11 @@ struct rtmc_scene {
     bool has_aligned = false;       // some medium has aligned acceptor dyes: the kernels with that code are used
     bool has_shapes = false;        // some element is not a rectangle, or is a lens
     bool has_area = false;          // the source spreads its launch points: the kernel with every feature is used
+    bool has_spectra = false;       // spectrum source or a detector with an efficiency table
     int features() const
     {
-        return has_area ? (FEAT_ALIGNED | FEAT_SHAPES | FEAT_AREA) : (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0);
+        if (has_area) return FEAT_ALL;
+        return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0) | (has_spectra ? FEAT_SPECTRA : 0);
     }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
@@ -901,6 +903,9 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     s->has_aligned = has_aligned;
     s->has_shapes = has_shapes;
     s->has_area = src.area[0] != 0.0 || src.area[1] != 0.0;
+    s->has_spectra = src.wavelength_mode == 1;
+    for (int i = 0; i < d->n_elements; i++)
+        if (d->elements[i].type == RTMC_TYPE_DUMP && d->elements[i].eqe_table >= 0) s->has_spectra = true;
     s->elements.assign(d->elements, d->elements + d->n_elements);
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
@@ -990,7 +995,11 @@ static const void *trace_function(int features)
     case 1: return (const void *)trace_kernel<real, 1>;
     case 2: return (const void *)trace_kernel<real, 2>;
     case 3: return (const void *)trace_kernel<real, 3>;
-    default: return (const void *)trace_kernel<real, FEAT_ALIGNED | FEAT_SHAPES | FEAT_AREA>;
+    case FEAT_SPECTRA | 0: return (const void *)trace_kernel<real, FEAT_SPECTRA | 0>;
+    case FEAT_SPECTRA | 1: return (const void *)trace_kernel<real, FEAT_SPECTRA | 1>;
+    case FEAT_SPECTRA | 2: return (const void *)trace_kernel<real, FEAT_SPECTRA | 2>;
+    case FEAT_SPECTRA | 3: return (const void *)trace_kernel<real, FEAT_SPECTRA | 3>;
+    default: return (const void *)trace_kernel<real, FEAT_ALL>;
     }
 }
 

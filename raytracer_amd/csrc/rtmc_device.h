@@ -187,7 +187,11 @@ struct HotScene {
 // FEAT_AREA (launch points spread over a rectangle) is only instantiated together
 // with the other two: such a source is rare, and a wave-uniform branch in the
 // lean kernels would still cost them the scalar registers of a third Philox block.
-enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4 };
+// FEAT_SPECTRA: the source draws its wavelength from a spectrum or a detector
+// has an efficiency table.  Without it every photon starts at the one source
+// wavelength, the energy increment of a detected photon is a table entry, and no
+// detector draws; the kernels then hold neither that code nor its pointers.
+enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_ALL = 15 };
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -724,7 +728,7 @@ __device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_
 // words 0,1 direction, 2 polarisation angle, 3 free path.
 // Launch or re-emission of the lanes of a wave in one pass: the direction and
 // polarisation samplers are run once for both kinds of lane.
-template <bool ALIGNED, bool AREA, typename real>
+template <bool ALIGNED, bool AREA, bool SPECTRA, typename real>
 __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<real> &hot, const Lds<real> &lds,
                                              Photon<real> &p, Rng<real, false> &g, bool launching)
 {
@@ -742,7 +746,9 @@ __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<r
     if (!launching) dist = free_path<ALIGNED>(hot, lds, p.mat, lds.mats[p.mat].abs_slot, p, g.expo(3));
     if (launching) {
         p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
-        p.wid = s.wl_mode == 1 ? cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3)) : s.wid_fixed;
+        p.wid = s.wid_fixed;
+        if (SPECTRA && s.wl_mode == 1)
+            p.wid = cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3));
         if (AREA && s.has_area) {  // a block of its own: words 0, 1 = position along x, y
             g.block(0u, BLK_LAUNCH + 1u);
             p.Lx += (g.uniform(0) - real(0.5)) * s.area[0];
@@ -1099,7 +1105,7 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
 // Tally sinks -----------------------------------------------------------------
 // LdsTally: the trace kernel (workgroup accumulators in LDS, detector
 // histogram in HBM).  NoTally: the step-wise kernel.
-template <typename real>
+template <typename real, bool SPECTRA>
 struct LdsTally {
     unsigned long long *acc;
     uint32_t *hist;
@@ -1132,7 +1138,7 @@ struct LdsTally {
     __device__ __forceinline__ void dump(int el, int slot, int wid, int wid0, bool counted)
     {
         atomicAdd(&hist[slot * n_bins + bin[wid]], 1u);
-        unsigned long long e = fixed_source
+        unsigned long long e = (!SPECTRA || fixed_source)
             ? (unsigned long long)fx[wid]
             : (unsigned long long)__double2ll_rn(wl[wid0] / wl[wid] * RTMC_ENERGY_FX_SCALE);
         atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], e);
@@ -1175,14 +1181,14 @@ __device__ __forceinline__ void finish_absorbed_move(Photon<real> &p, Tally &tal
 
 // Elements.py:152-165: the tallies of the detector the photon ended on
 // (p.last_el); the efficiency draw is word 0 of the iteration's variates.
-template <typename real, bool TAPE, typename Tally>
+template <bool SPECTRA, typename real, bool TAPE, typename Tally>
 __device__ __forceinline__ void finish_dumped(const HotScene<real> &sc, const Lds<real> &lds, const Photon<real> &p,
                                               Rng<real, TAPE> &g, Tally &tally)
 {
     const int info = lds.elems[p.last_el].info;
     bool counted = true;
     const int eqe = (info & 0xFF) - 1;
-    if (eqe >= 0) counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
+    if (SPECTRA && eqe >= 0) counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
     tally.dump(p.last_el, info >> 8, p.wid, p.wid0, counted);
 }
 
@@ -1275,7 +1281,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
         }
         if (type == RTMC_TYPE_DUMP) {  // Elements.py:152-169
             p.status = RTMC_ST_DUMPED;
-            if (!DEFER_ENDINGS) finish_dumped(sc, lds, p, g, tally);
+            if (!DEFER_ENDINGS) finish_dumped<(FEATURES & FEAT_SPECTRA) != 0>(sc, lds, p, g, tally);
             p.flags |= F_WAS_EL;
             p.iter++;
             return STEP_ENDED;
