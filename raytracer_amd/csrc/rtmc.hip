@@ -179,7 +179,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 const DevAbs<real> &a = lds.abs[m.abs_slot * hot.n_wid + p.wid];
                 const bool in_donor = absorbed_by_donor<ALIGNED>(m, a, p, g);
                 uint32_t v_lambda;
-                const int outcome = fret_decide(m, g, in_donor, (uint32_t)p.iter, v_lambda);
+                const int outcome = fret_decide<(FEATURES & FEAT_BACK) != 0>(m, g, in_donor, (uint32_t)p.iter, v_lambda);
                 if (outcome != 0) {  // one pick for both dyes: the table is chosen per lane
                     const bool donor = outcome == 1;
                     const int off = donor ? m.cdfD_off : m.cdfA_off, len = donor ? m.cdfD_len : m.cdfA_len;
@@ -492,6 +492,7 @@ struct DeviceImage {
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
     DevSource<real> src;
+    bool back_possible = false;  // some medium's thresholds let the acceptor hand the excitation back
 };
 
 struct PerDevice {
@@ -519,10 +520,12 @@ struct rtmc_scene {
     bool has_shapes = false;        // some element is not a rectangle, or is a lens
     bool has_area = false;          // the source spreads its launch points: the kernel with every feature is used
     bool has_spectra = false;       // spectrum source or a detector with an efficiency table
+    bool has_back = false;          // some medium's acceptor can hand the excitation back to its donor
     int features() const
     {
         if (has_area) return FEAT_ALL;
-        return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0) | (has_spectra ? FEAT_SPECTRA : 0);
+        return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0) | (has_spectra ? FEAT_SPECTRA : 0) |
+               (has_back ? FEAT_BACK : 0);
     }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
@@ -680,6 +683,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
             o.pT[j] = j < o.n_p ? threshold32(c / sp) : 0xFFFFFFFFu;
             o.pAT[j] = spa > 0 ? threshold32(ca / spa) : 0xFFFFFFFFu;
         }
+        // the acceptor pathway draw is a multiple of 256: a threshold above the largest such value is never reached
+        if (o.n_p == 3 && o.pAT[1] <= 0xFFFFFF00u) img.back_possible = true;
         o.cdfD_off = cdf_off[mat_cdfD[i]]; o.cdfD_len = (int)cdfs[mat_cdfD[i]].size();
         o.widD_off = cdf_wid_off[mat_cdfD[i]];
         o.cdfA_off = cdf_off[mat_cdfA[i]]; o.cdfA_len = (int)cdfs[mat_cdfA[i]].size();
@@ -945,6 +950,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     }
     build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img32);
     build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img64);
+    s->has_back = s->img32.back_possible || s->img64.back_possible;
     if (s->img32.lay.total > 160 * 1024) {
         size_t need = s->img32.lay.total;
         delete s;
@@ -986,20 +992,33 @@ RTMC_API int rtmc_scene_wavelengths(const rtmc_scene *s, int64_t *count, double 
 
 static int upload_scene_structs(rtmc_scene *s, PerDevice &p);
 
-// the trace kernel instantiation for a feature set
+// The trace kernel instantiation for a feature set.  float32: every combination
+// of aligned dyes, other shapes, spectra and back transfer, plus the one with
+// everything (launch area).  float64 (validation only): spectra and back
+// transfer always on, which keeps the number of slow-to-compile kernels down.
+template <typename real, int BASE>
+static const void *trace_variant(int features)
+{
+    switch (features & (FEAT_ALIGNED | FEAT_SHAPES)) {
+    case 0: return (const void *)trace_kernel<real, BASE | 0>;
+    case 1: return (const void *)trace_kernel<real, BASE | 1>;
+    case 2: return (const void *)trace_kernel<real, BASE | 2>;
+    default: return (const void *)trace_kernel<real, BASE | 3>;
+    }
+}
 template <typename real>
 static const void *trace_function(int features)
 {
-    switch (features) {
-    case 0: return (const void *)trace_kernel<real, 0>;
-    case 1: return (const void *)trace_kernel<real, 1>;
-    case 2: return (const void *)trace_kernel<real, 2>;
-    case 3: return (const void *)trace_kernel<real, 3>;
-    case FEAT_SPECTRA | 0: return (const void *)trace_kernel<real, FEAT_SPECTRA | 0>;
-    case FEAT_SPECTRA | 1: return (const void *)trace_kernel<real, FEAT_SPECTRA | 1>;
-    case FEAT_SPECTRA | 2: return (const void *)trace_kernel<real, FEAT_SPECTRA | 2>;
-    case FEAT_SPECTRA | 3: return (const void *)trace_kernel<real, FEAT_SPECTRA | 3>;
-    default: return (const void *)trace_kernel<real, FEAT_ALL>;
+    if (features & FEAT_AREA) return (const void *)trace_kernel<real, FEAT_ALL>;
+    if constexpr (sizeof(real) == 8) {
+        return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);
+    } else {
+        switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+        case 0: return trace_variant<real, 0>(features);
+        case FEAT_SPECTRA: return trace_variant<real, FEAT_SPECTRA>(features);
+        case FEAT_BACK: return trace_variant<real, FEAT_BACK>(features);
+        default: return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);
+        }
     }
 }
 

@@ -191,7 +191,10 @@ struct HotScene {
 // has an efficiency table.  Without it every photon starts at the one source
 // wavelength, the energy increment of a detected photon is a table entry, and no
 // detector draws; the kernels then hold neither that code nor its pointers.
-enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_ALL = 15 };
+// FEAT_BACK: some medium allows the back transfer acceptor -> donor
+// (MonteCarloFRET.py:187-190), which reopens the pathway choice with a Philox
+// block of its own in a loop.
+enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_BACK = 16, FEAT_ALL = 31 };
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -571,7 +574,7 @@ __device__ __forceinline__ void launch_in_reference_order(SceneArg<real> sc, con
 // transfer opens the next block of this iteration.  Returns 0: internal conversion,
 // 1: donor fluoresces, 2: acceptor fluoresces; `v_lambda` is the wavelength
 // uniform in Philox mode (in tape mode it is drawn later, in reference order).
-template <typename real, bool TAPE>
+template <bool BACK, typename real, bool TAPE>
 __device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE> &g, bool in_donor,
                                            uint32_t iter, uint32_t &v_lambda)
 {
@@ -590,7 +593,7 @@ __device__ __forceinline__ int fret_decide(const DevMat<real> &m, Rng<real, TAPE
         uint32_t va = g.u32(2);  // :119
         int pa = (va >= m.pAT[0]) + (va >= m.pAT[1]);
         if (pa == 0) return 2;   // :170-175
-        if (pa == 1) return 0;   // :182-185
+        if (!BACK || pa == 1) return 0;  // :182-185 (without BACK no threshold of the scene lets pa reach 2)
         in_donor = true;         // :187-190 back transfer
     }
 }
@@ -657,7 +660,7 @@ __device__ __forceinline__ void emit_in_reference_order(const HotScene<real> &sc
     const DevAbs<real> &a = lds.abs[m.abs_slot * sc.n_wid + p.wid];
     bool in_donor = absorbed_by_donor<true>(m, a, p, g);  // PhotonObject.py:244
     uint32_t v_lambda;
-    int outcome = fret_decide(m, g, in_donor, 0u, v_lambda);
+    int outcome = fret_decide<true>(m, g, in_donor, 0u, v_lambda);
     if (outcome == 2 && (m.flags & 2)) {  // MonteCarloFRET.py:124-162
         const DevOrient<real> &o = lds.orient[p.mat];
         real sx, cx, s_az, c_az, s_phi, c_phi, s_ph = real(0), c_ph = real(1);
