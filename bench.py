@@ -102,7 +102,8 @@ def main():
 
     block = sc.new_tallies(n_el)
     # set-up, not a step: device context, scene tables into HBM, kernel code object
-    scene.run(1024, seed=args.seed ^ 0x5EED, first_photon=0, device=device, tallies=sc.new_tallies(n_el))
+    # (a call for zero photons prepares the device and launches nothing)
+    scene.run(0, seed=args.seed, first_photon=0, device=device, tallies=sc.new_tallies(n_el))
     for w in range(args.warmup):
         scene.run(per_step, seed=args.seed, first_photon=first_id(w), device=device,
                   tallies=sc.new_tallies(n_el))
