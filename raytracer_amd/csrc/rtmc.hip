@@ -113,8 +113,16 @@ constexpr int RENEW_DEBT = RTMC_RENEW_DEBT;  // lane-iterations
 #ifndef RTMC_TRACE_WAVES
 #define RTMC_TRACE_WAVES 6
 #endif
+// Workgroup size: 512 threads when three workgroups fit a CU.  A scene whose
+// tables leave room for only two or one (a source spectrum adds a row per
+// wavelength to every per-wavelength table) gets 768 or 1024 threads per
+// workgroup instead, so that the SIMDs still hold six or four waves; the host
+// picks the size per scene and the float32 kernels are compiled to be launched
+// with any of them.  (Wave counts that are not a multiple of four per workgroup
+// would leave workgroups unplaceable.)
+constexpr int TRACE_BLOCK_MAX = 1024;
 template <typename real, int FEATURES>
-__global__ void __launch_bounds__(TRACE_BLOCK)
+__global__ void __launch_bounds__(sizeof(real) == 4 ? TRACE_BLOCK_MAX : TRACE_BLOCK)
 __attribute__((amdgpu_waves_per_eu((sizeof(real) == 4 ? RTMC_TRACE_WAVES : 1), (sizeof(real) == 4 ? RTMC_TRACE_WAVES : 4))))
 trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t first, uint64_t n,
              unsigned long long *work)
@@ -510,6 +518,7 @@ struct PerDevice {
     size_t tally_words = 0;
     double last_ms = 0;
     int max_blocks32 = 0, max_blocks64 = 0, n_cu = 0;
+    int block32 = TRACE_BLOCK;  // threads per workgroup of the float32 trace kernel for this scene
 };
 
 }  // namespace
@@ -1090,7 +1099,21 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     const void *trace64 = trace_function<double>(s->features());
     HIP_TRY(hipFuncSetAttribute(trace32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
     HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks32, trace32, TRACE_BLOCK, s->img32.lay.total));
+    {  // the workgroup size that puts the most waves on a SIMD; the smaller one on a tie
+        int best_waves = -1;
+        for (int block = TRACE_BLOCK; block <= TRACE_BLOCK_MAX; block += 256) {
+            int n = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace32, block, s->img32.lay.total));
+            if (n * block > best_waves) { best_waves = n * block; p.max_blocks32 = n; p.block32 = block; }
+        }
+        if (const char *e = getenv("RTMC_TRACE_THREADS")) {  // experiments
+            const int block = atoi(e);
+            if (block >= 256 && block <= TRACE_BLOCK_MAX && block % 256 == 0) {
+                p.block32 = block;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks32, trace32, block, s->img32.lay.total));
+            }
+        }
+    }
     if (s->img64.lay.total <= 160 * 1024) {
         HIP_TRY(hipFuncSetAttribute(trace64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
         HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
@@ -1192,7 +1215,8 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
 
     // enough waves to fill the machine, never more than there are blocks of ids
     uint64_t wanted = (n_photons + 63) / 64;                          // waves
-    wanted = (wanted + TRACE_BLOCK / 64 - 1) / (TRACE_BLOCK / 64);    // workgroups
+    const int block = f32 ? p.block32 : TRACE_BLOCK;
+    wanted = (wanted + block / 64 - 1) / (block / 64);                // workgroups
     uint64_t resident = (uint64_t)p.n_cu * (uint64_t)per_cu;
     if (const char *cap = getenv("RTMC_WG_PER_CU"))  // experiments: fewer resident workgroups than fit
         resident = (uint64_t)p.n_cu * (uint64_t)std::max(1, std::min(per_cu, atoi(cap)));
@@ -1200,7 +1224,7 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
 
     if (getenv("RTMC_DEBUG"))
         fprintf(stderr, "[rtmc] trace launch: %u workgroups of %d threads (%d per CU x %d CUs), %zu B LDS, %llu photons\n",
-                grid, TRACE_BLOCK, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
+                grid, block, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
     HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
 #ifdef RTMC_PROFILE_SECTIONS
     HIP_TRY(hipMemsetAsync(p.work, 0, 256, p.stream));
@@ -1213,7 +1237,7 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
         unsigned long long *work = p.work;
         void *args[] = {&scene_ptr, &tl, &seed, &first_photon, &n_photons, &work};
         const void *fn = f32 ? trace_function<float>(s->features()) : trace_function<double>(s->features());
-        HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(TRACE_BLOCK), args, lds_bytes, p.stream));
+        HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(block), args, lds_bytes, p.stream));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p.ev1, p.stream));

@@ -22,7 +22,10 @@ rows = []
 for name in ["C1_open", "C1", "C2", "C3", "C4", "C5", "C6", "C7", "C8", "C9", "C2r"]:
     rt = H.raytrace_for(name)
     s = rt.Scene()
-    n = int(n_default if name not in ("C1_open", "C8") else n_default / 50)
+    # photons that run to the 10001-iteration cap set a floor on the kernel time (one
+    # photon is 10001 sequential iterations): C4 needs more photons than the others
+    # before that tail stops showing, C1_open and C8 are dominated by it anyway
+    n = int(n_default / 50 if name in ("C1_open", "C8") else n_default * 8 if name == "C4" else n_default)
     s.run(min(n, 1000000), seed=3)                      # warm-up, scene upload
     ms, wall = 1e30, 1e30
     for rep in range(3):                                # same seed, same tallies: best of three timings
