@@ -941,7 +941,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     for (int i = 0; i < s->n_el; i++)
         if (d->elements[i].type == RTMC_TYPE_DUMP) s->el_slot[i] = s->n_dump++;
     // Elements.py:158 EnergyCounter += wl_start / wl, in units of 2^-24, for a single source line
-    s->energy_fx.assign(wl.size(), 0u);
+    // (a source with a spectrum has no such table: the kernels divide the two wavelengths)
+    s->energy_fx.assign(src.wavelength_mode == 0 ? wl.size() : 1, 0u);
     if (src.wavelength_mode == 0)
         for (size_t w = 0; w < wl.size(); w++) {
             double fx = std::llrint(wl[0] / wl[w] * RTMC_ENERGY_FX_SCALE);
