@@ -16,7 +16,8 @@
  *   - lengths in cm, wavelengths in nm, concentrations in mmol/L (the units
  *     of the reference's job files);
  *   - a scene handle is immutable after creation and may be used from several
- *     host threads, one device each.
+ *     host threads; calls on different devices run concurrently, calls on the
+ *     same device are run one after the other by the library.
  */
 #ifndef RTMC_H
 #define RTMC_H

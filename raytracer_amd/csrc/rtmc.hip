@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -407,17 +408,32 @@ __global__ void intersect_kernel(const DevScene<real> *scene, uint32_t n, const 
 // ---------------------------------------------------------------------------
 // host: errors
 // ---------------------------------------------------------------------------
-static thread_local std::string g_error;
+// fixed storage: reporting a failure allocates nothing
+static thread_local char g_error[512] = "";
 
 static int fail(int code, const char *fmt, ...)
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
     va_end(ap);
-    g_error = buf;
     return code;
+}
+
+// Nothing may propagate out of an entry point: allocation failures and
+// anything else thrown by the host code become error codes.
+template <typename Body>
+static int guarded(Body &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(RTMC_ENOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(RTMC_EINVAL, "%s", e.what());
+    } catch (...) {
+        return fail(RTMC_EINVAL, "unexpected exception");
+    }
 }
 
 #define HIP_TRY(expr)                                                                         \
@@ -515,12 +531,27 @@ struct PerDevice {
     uint32_t *eqeT = nullptr;
     unsigned long long *tallies = nullptr;  // scalars | bounce | spectral | energy | hist
     unsigned long long *work = nullptr;
+    unsigned long long *host_tallies = nullptr;  // pinned host copy of `tallies`, filled after every launch
     size_t tally_words = 0;
     double last_ms = 0;
     int max_blocks32 = 0, max_blocks64 = 0, n_cu = 0;
     int block32 = TRACE_BLOCK;  // threads per workgroup of the float32 trace kernel for this scene
 };
 
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// per-GPU state shared by every scene of the process
+// ---------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 64;
+namespace {
+struct GpuShared {
+    // Held from the first memset of a launch to the end of its copy-back: the
+    // calls of one process on one GPU run one after the other (the calls on one
+    // scene share its tally buffers, stream and events).  Calls on different GPUs do not wait for each other.
+    std::mutex launch_mu;
+};
+GpuShared g_gpu[MAX_DEVICES];
 }  // namespace
 
 struct rtmc_scene {
@@ -814,16 +845,25 @@ int get_table(const rtmc_scene_desc *d, rtmc_table ref, HostTable &t, const char
 }  // namespace
 
 RTMC_API int rtmc_version(void) { return RTMC_ABI_VERSION; }
-RTMC_API const char *rtmc_last_error(void) { return g_error.c_str(); }
+RTMC_API const char *rtmc_last_error(void) { return g_error; }
+
+static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out);
 
 RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
 {
     if (!d || !out) return fail(RTMC_EINVAL, "null argument");
     *out = nullptr;
+    return guarded([&] { return scene_create_impl(d, out); });
+}
+
+static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
+{
     if (d->abi_version != RTMC_ABI_VERSION)
         return fail(RTMC_EINVAL, "description has ABI version %d, library %d", d->abi_version, RTMC_ABI_VERSION);
     if (d->n_elements < 1 || d->n_elements > 255) return fail(RTMC_ELIMIT, "1..255 elements supported, got %d", d->n_elements);
-    if (d->n_tables > 254) return fail(RTMC_ELIMIT, "at most 254 detection tables supported, got %d", d->n_tables);
+    if (d->n_tables < 0 || d->n_tables > 254) return fail(RTMC_ELIMIT, "0..254 detection tables supported, got %d", d->n_tables);
+    if (d->n_tables > 0 && !d->tables) return fail(RTMC_EINVAL, "null detection table array");
+    if (d->table_data_len < 0 || (d->table_data_len > 0 && !d->table_data)) return fail(RTMC_EINVAL, "null or negative table data");
     if (d->n_materials < 1 || d->n_materials > 255) return fail(RTMC_ELIMIT, "1..255 materials supported, got %d", d->n_materials);
     if (d->max_iterations < 1) return fail(RTMC_EINVAL, "max_iterations must be positive");
     if (!d->elements || !d->materials) return fail(RTMC_EINVAL, "null element or material array");
@@ -849,7 +889,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
         if (e.type == RTMC_TYPE_INTERFACE &&
             (e.material1 < 0 || e.material1 >= d->n_materials || e.material2 < 0 || e.material2 >= d->n_materials))
             return fail(RTMC_EINVAL, "element %d: interface material out of range", i);
-        if (e.type == RTMC_TYPE_DUMP && e.eqe_table >= d->n_tables)
+        if (e.type == RTMC_TYPE_DUMP && (e.eqe_table < -1 || e.eqe_table >= d->n_tables))
             return fail(RTMC_EINVAL, "element %d: detection table out of range", i);
     }
 
@@ -912,7 +952,8 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
         run += (int)cdfs[i].size();
     }
 
-    rtmc_scene *s = new rtmc_scene;
+    std::unique_ptr<rtmc_scene> holder(new rtmc_scene);
+    rtmc_scene *s = holder.get();
     s->n_el = d->n_elements; s->n_mat = d->n_materials; s->n_eqe = d->n_tables; s->max_iter = d->max_iterations;
     s->has_aligned = has_aligned;
     s->has_shapes = has_shapes;
@@ -946,7 +987,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     if (src.wavelength_mode == 0)
         for (size_t w = 0; w < wl.size(); w++) {
             double fx = std::llrint(wl[0] / wl[w] * RTMC_ENERGY_FX_SCALE);
-            if (fx > 4294967295.0) { delete s; return fail(RTMC_ELIMIT, "wavelength ratio %g too large", wl[0] / wl[w]); }
+            if (fx > 4294967295.0) return fail(RTMC_ELIMIT, "wavelength ratio %g too large", wl[0] / wl[w]);
             s->energy_fx[w] = (uint32_t)fx;
         }
     // detection thresholds, Elements.py:164
@@ -954,7 +995,7 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     for (int t = 0; t < d->n_tables; t++) {
         HostTable q;
         int rc = get_table(d, d->tables[t], q, "detection spectrum");
-        if (rc) { delete s; return rc; }
+        if (rc) return rc;
         for (size_t w = 0; w < wl.size(); w++)
             s->eqeT[(size_t)t * wl.size() + w] = threshold32(q.y[nearest_index(q.x, wl[w])]);
     }
@@ -963,10 +1004,9 @@ RTMC_API int rtmc_scene_create(const rtmc_scene_desc *d, rtmc_scene **out)
     s->has_back = s->img32.back_possible || s->img64.back_possible;
     if (s->img32.lay.total > 160 * 1024) {
         size_t need = s->img32.lay.total;
-        delete s;
         return fail(RTMC_ELIMIT, "scene tables need %zu bytes of LDS, 163840 available", need);
     }
-    *out = s;
+    *out = holder.release();
     return RTMC_OK;
 }
 
@@ -974,6 +1014,7 @@ static void free_device(PerDevice &p)
 {
     if (p.ro_block) (void)hipFree(p.ro_block);
     if (p.rw_block) (void)hipFree(p.rw_block);
+    if (p.host_tallies) (void)hipHostFree(p.host_tallies);
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
     if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -1046,7 +1087,8 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
 {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));
-    if (device < 0 || device >= count) return fail(RTMC_EINVAL, "device %d out of range (%d visible)", device, count);
+    if (device < 0 || device >= count || device >= MAX_DEVICES)
+        return fail(RTMC_EINVAL, "device %d out of range (%d visible, at most %d supported)", device, count, MAX_DEVICES);
     HIP_TRY(hipSetDevice(device));
     std::lock_guard<std::mutex> lock(s->mu);
     PerDevice &p = s->dev[device];
@@ -1093,6 +1135,7 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     HIP_TRY(hipMalloc(&p.rw_block, round_up(8 * p.tally_words) + 4096));
     p.tallies = (unsigned long long *)p.rw_block;
     p.work = (unsigned long long *)((char *)p.rw_block + round_up(8 * p.tally_words));
+    HIP_TRY(hipHostMalloc((void **)&p.host_tallies, 8 * p.tally_words, hipHostMallocDefault));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     p.n_cu = prop.multiProcessorCount;
@@ -1156,39 +1199,22 @@ static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, cons
     return sc;
 }
 
-static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
-                      uint64_t n_photons, rtmc_tallies *out);
 RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device);
 
 // A workgroup counts detector hits in 32-bit LDS words; a launch is kept small
 // enough that no workgroup can come near 2^32 photons.
 static const uint64_t MAX_PHOTONS_PER_LAUNCH = 100000000000ull;
 
-RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
-                        uint64_t n_photons, rtmc_tallies *out)
+static uint64_t photons_per_launch_cap()
 {
     uint64_t cap = MAX_PHOTONS_PER_LAUNCH;
     if (const char *e = getenv("RTMC_MAX_PHOTONS_PER_LAUNCH"))  // tests exercise the splitting with a small value
         cap = std::max<uint64_t>(1, std::min<uint64_t>(cap, strtoull(e, nullptr, 10)));
-    if (n_photons <= cap) return run_launch(s, device, precision, seed, first_photon, n_photons, out);
-    if (first_photon + n_photons < first_photon) return fail(RTMC_EINVAL, "photon id range wraps");
-    double ms = 0;
-    for (uint64_t done = 0; done < n_photons;) {
-        const uint64_t part = std::min(cap, n_photons - done);
-        int rc = run_launch(s, device, precision, seed, first_photon + done, part, out);
-        if (rc) return rc;
-        ms += rtmc_last_kernel_ms(s, device);
-        done += part;
-    }
-    {
-        std::lock_guard<std::mutex> lock(s->mu);
-        s->dev[device].last_ms = ms;
-    }
-    return RTMC_OK;
+    return cap;
 }
 
-static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
-                      uint64_t n_photons, rtmc_tallies *out)
+static int check_run_arguments(const rtmc_scene *s, int precision, uint64_t first_photon, uint64_t n_photons,
+                               const rtmc_tallies *out)
 {
     if (!s || !out) return fail(RTMC_EINVAL, "null argument");
     if (out->n_elements != s->n_el) return fail(RTMC_EINVAL, "tally block is for %d elements, scene has %d", out->n_elements, s->n_el);
@@ -1196,19 +1222,24 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
         return fail(RTMC_EINVAL, "tally block has a null array");
     if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
     if (first_photon + n_photons < first_photon) return fail(RTMC_EINVAL, "photon id range wraps");
-    DeviceGuard restore_device;
-    PerDevice *pp;
-    int rc = prepare_device(s, device, &pp);
-    if (rc) return rc;
-    PerDevice &p = *pp;
-    if (n_photons == 0) return RTMC_OK;
+    return RTMC_OK;
+}
+
+// One launch of the trace kernel with the device tally block at `dev_tallies`
+// (p.tally_words words) and the work counter at `dev_work`, then the copy-back
+// through the scene's pinned staging buffer and the fold into the caller's
+// block.  The device of `p` is current.  Allocates nothing.
+static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned long long *dev_tallies,
+                           unsigned long long *dev_work, int precision, uint64_t seed, uint64_t first_photon,
+                           uint64_t n_photons, rtmc_tallies *out, double *kernel_ms)
+{
     const bool f32 = precision == RTMC_F32;
     const size_t lds_bytes = f32 ? s->img32.lay.total : s->img64.lay.total;
     const int per_cu = f32 ? p.max_blocks32 : p.max_blocks64;
     if (per_cu < 1) return fail(RTMC_ELIMIT, "scene tables (%zu bytes) do not fit the LDS in this precision", lds_bytes);
 
     DevTallies tl;
-    tl.scalars = p.tallies;
+    tl.scalars = dev_tallies;
     tl.bounce = tl.scalars + ACC_SCALARS;
     tl.spectral = tl.bounce + s->n_el;
     tl.energy_fx = tl.spectral + s->n_el;
@@ -1226,32 +1257,32 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
     if (getenv("RTMC_DEBUG"))
         fprintf(stderr, "[rtmc] trace launch: %u workgroups of %d threads (%d per CU x %d CUs), %zu B LDS, %llu photons\n",
                 grid, block, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
-    HIP_TRY(hipMemsetAsync(p.tallies, 0, 8 * p.tally_words, p.stream));
+    std::lock_guard<std::mutex> serial(g_gpu[device].launch_mu);
+    HIP_TRY(hipMemsetAsync(dev_tallies, 0, 8 * p.tally_words, p.stream));
 #ifdef RTMC_PROFILE_SECTIONS
-    HIP_TRY(hipMemsetAsync(p.work, 0, 256, p.stream));
+    HIP_TRY(hipMemsetAsync(dev_work, 0, 256, p.stream));
 #else
-    HIP_TRY(hipMemsetAsync(p.work, 0, 8, p.stream));
+    HIP_TRY(hipMemsetAsync(dev_work, 0, 8, p.stream));
 #endif
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
     {
         const void *scene_ptr = f32 ? p.scene32 : p.scene64;
-        unsigned long long *work = p.work;
+        unsigned long long *work = dev_work;
         void *args[] = {&scene_ptr, &tl, &seed, &first_photon, &n_photons, &work};
         const void *fn = f32 ? trace_function<float>(s->features()) : trace_function<double>(s->features());
         HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(block), args, lds_bytes, p.stream));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(p.ev1, p.stream));
-    std::vector<unsigned long long> host(p.tally_words);
-    HIP_TRY(hipMemcpyAsync(host.data(), p.tallies, 8 * p.tally_words, hipMemcpyDeviceToHost, p.stream));
+    HIP_TRY(hipMemcpyAsync(p.host_tallies, dev_tallies, 8 * p.tally_words, hipMemcpyDeviceToHost, p.stream));
     HIP_TRY(hipStreamSynchronize(p.stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, p.ev0, p.ev1));
-    p.last_ms = ms;
+    *kernel_ms += ms;
 #ifdef RTMC_PROFILE_SECTIONS
     {
         unsigned long long w[18];
-        HIP_TRY(hipMemcpy(w, p.work, sizeof w, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(w, dev_work, sizeof w, hipMemcpyDeviceToHost));
         fprintf(stderr, "[rtmc] sections: renew %llu passes, %.0f cycles each, %.1f lanes; step %llu passes, %.0f cycles each, %.1f lanes; "
                         "renew share of wave time %.3f\n",
                 w[9], (double)w[8] / (double)std::max(1ull, w[9]), (double)w[10] / (double)std::max(1ull, w[9]),
@@ -1263,7 +1294,7 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
     }
 #endif
 
-    const unsigned long long *sc = host.data();
+    const unsigned long long *sc = p.host_tallies;
     const unsigned long long *bounce = sc + ACC_SCALARS, *spectral = bounce + s->n_el,
                              *energy = spectral + s->n_el, *hist = energy + s->n_el;
     const size_t n_bins = s->bins_used.size();
@@ -1296,6 +1327,34 @@ static int run_launch(rtmc_scene *s, int device, int precision, uint64_t seed, u
     return RTMC_OK;
 }
 
+static void set_last_kernel_ms(rtmc_scene *s, PerDevice &p, double ms)
+{
+    std::lock_guard<std::mutex> lock(s->mu);
+    p.last_ms = ms;
+}
+
+RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                        uint64_t n_photons, rtmc_tallies *out)
+{
+    return guarded([&]() -> int {
+        int rc = check_run_arguments(s, precision, first_photon, n_photons, out);
+        if (rc) return rc;
+        DeviceGuard restore_device;
+        PerDevice *pp;
+        if ((rc = prepare_device(s, device, &pp))) return rc;
+        const uint64_t cap = photons_per_launch_cap();
+        double ms = 0;
+        for (uint64_t done = 0; done < n_photons;) {
+            const uint64_t part = std::min(cap, n_photons - done);
+            rc = launch_and_fold(s, *pp, device, pp->tallies, pp->work, precision, seed, first_photon + done, part, out, &ms);
+            if (rc) return rc;
+            done += part;
+        }
+        if (n_photons) set_last_kernel_ms(s, *pp, ms);
+        return RTMC_OK;
+    });
+}
+
 RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device)
 {
     if (!s) return -1.0;
@@ -1319,7 +1378,9 @@ RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n
                               const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
                               double *trace)
 {
-    return step_tape_impl(s, device, precision, n, b, tape, tape_off, n_steps, launch, trace, nullptr, nullptr, nullptr);
+    return guarded([&] {
+        return step_tape_impl(s, device, precision, n, b, tape, tape_off, n_steps, launch, trace, nullptr, nullptr, nullptr);
+    });
 }
 
 RTMC_API int rtmc_op_crossing(rtmc_scene *s, int device, int precision, uint32_t n, const rtmc_photon_soa *b,
@@ -1327,10 +1388,12 @@ RTMC_API int rtmc_op_crossing(rtmc_scene *s, int device, int precision, uint32_t
 {
     if (!element || !distance || !points) return fail(RTMC_EINVAL, "null argument");
     if (n == 0) return RTMC_OK;
-    const double no_tape = 0.0;
-    std::vector<uint64_t> off(n + 1, 0);
-    return step_tape_impl(s, device, precision, n, const_cast<rtmc_photon_soa *>(b), &no_tape, off.data(), 0, 0,
-                          nullptr, element, distance, points);
+    return guarded([&] {
+        const double no_tape = 0.0;
+        std::vector<uint64_t> off(n + 1, 0);
+        return step_tape_impl(s, device, precision, n, const_cast<rtmc_photon_soa *>(b), &no_tape, off.data(), 0, 0,
+                              nullptr, element, distance, points);
+    });
 }
 
 static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
@@ -1341,6 +1404,16 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
     if (!s || !b || !tape || !tape_off) return fail(RTMC_EINVAL, "null argument");
     if (precision != RTMC_F32 && precision != RTMC_F64) return fail(RTMC_EINVAL, "unknown precision %d", precision);
     if (n == 0) return RTMC_OK;
+    {   // the columns this call reads or writes must exist
+        bool ok = b->last_element && b->was_element && b->reflected;
+        for (int j = 0; j < 3; j++) ok = ok && b->loc[j] && b->dir[j] && b->old_point[j];
+        if (!crossing) {
+            ok = ok && b->wavelength && b->start_wavelength && b->dist_left && b->hit_distance && b->psi && b->material &&
+                 b->status && b->iterations && b->tape_pos;
+            for (int j = 0; j < 3; j++) ok = ok && b->efield[j];
+        }
+        if (!ok) return fail(RTMC_EINVAL, "photon batch has a null column");
+    }
     for (uint32_t k = 0; k < n; k++) {
         if (tape_off[k + 1] < tape_off[k]) return fail(RTMC_EINVAL, "tape offsets must ascend");
         if (tape_off[k + 1] - tape_off[k] > 0x7FFFFFFFull) return fail(RTMC_ELIMIT, "tape segment too long");
@@ -1366,7 +1439,7 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
                     return fail(RTMC_EINVAL, "photon %u carries a wavelength that is neither a source line nor an emission-table row", k);
                 wid[k] = a->second; wid0[k] = c->second;
             }
-            if (b->material[k] < 0 || b->material[k] >= s->n_mat) return fail(RTMC_EINVAL, "photon %u: material out of range", k);
+            if (!crossing && (b->material[k] < 0 || b->material[k] >= s->n_mat)) return fail(RTMC_EINVAL, "photon %u: material out of range", k);
             if (b->last_element[k] < -1 || b->last_element[k] >= s->n_el) return fail(RTMC_EINVAL, "photon %u: element out of range", k);
             uint64_t seg = tape_off[k + 1] - tape_off[k];
             if (!crossing && (b->tape_pos[k] < 0 || (uint64_t)b->tape_pos[k] > seg)) return fail(RTMC_EINVAL, "photon %u: tape position outside its segment", k);
@@ -1406,7 +1479,13 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
     sd.iterations = icols[7]; sd.tape_pos = icols[8];
     const int32_t *isrc[ni] = {wid.data(), wid0.data(), b->material, b->status, b->last_element,
                                b->was_element, b->reflected, b->iterations, b->tape_pos};
-    if (!launch) {
+    std::lock_guard<std::mutex> serial(g_gpu[device].launch_mu);
+    if (crossing) {  // only position, direction, old point and the three flags of the last element are read
+        HIP_TRY(hipMemsetAsync(dd, 0, 8 * nd * (size_t)n, p.stream));
+        HIP_TRY(hipMemsetAsync(ii, 0, 4 * ni * (size_t)n, p.stream));
+        for (size_t j : {0, 1, 2, 3, 4, 5, 9, 10, 11}) HIP_TRY(hipMemcpyAsync(dd + j * n, hsrc[j], 8 * (size_t)n, hipMemcpyHostToDevice, p.stream));
+        for (size_t j : {4, 5, 6}) HIP_TRY(hipMemcpyAsync(icols[j], isrc[j], 4 * (size_t)n, hipMemcpyHostToDevice, p.stream));
+    } else if (!launch) {
         for (size_t j = 0; j < nd; j++) HIP_TRY(hipMemcpyAsync(dd + j * n, hsrc[j], 8 * (size_t)n, hipMemcpyHostToDevice, p.stream));
         for (size_t j = 0; j < ni; j++) HIP_TRY(hipMemcpyAsync(icols[j], isrc[j], 4 * (size_t)n, hipMemcpyHostToDevice, p.stream));
     }
@@ -1464,6 +1543,7 @@ RTMC_API int rtmc_op_intersect(rtmc_scene *s, int device, int precision, uint32_
     int rc = prepare_device(s, device, &pp);
     if (rc) return rc;
     PerDevice &p = *pp;
+    std::lock_guard<std::mutex> serial(g_gpu[device].launch_mu);
     DeviceBuffer dl, ddir, dout;
     const size_t total = (size_t)n * s->n_el;
     HIP_TRY(hipMalloc(&dl.ptr, 24 * (size_t)n));
