@@ -255,6 +255,28 @@ void rtmc_scene_destroy(rtmc_scene *scene);
 int rtmc_run(rtmc_scene *scene, int device, int precision, uint64_t seed,
              uint64_t first_photon, uint64_t n_photons, rtmc_tallies *out);
 
+/* rtmc_run for callers that cannot allocate: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
+ * in the reference.  Same arguments, same kernels and bit-identical tallies as
+ * rtmc_run, but the device tally block and the work counter -- the only device
+ * memory a trace needs beyond the resident scene -- live in a static array of
+ * the library (65536 64-bit tally words + the counter, 516 KB on every GPU the
+ * library is used on, held until the process ends) and the call allocates
+ * nothing, on the device or on the host.
+ *   - The scene must already be resident on `device`: one earlier rtmc_run on
+ *     it (for zero photons, if nothing is to be traced yet) uploads it.
+ *     Otherwise RTMC_EINVAL.
+ *   - A scene whose tally block (7 + 3 n_elements + detectors x distinct 1-nm
+ *     wavelength bins, in words) exceeds 65536 words is refused with
+ *     RTMC_ELIMIT; rtmc_run has no such limit.
+ *   - All calls on one GPU share that GPU's array; it is cleared at the start
+ *     of every launch and keeps nothing between calls.  The library runs the
+ *     calls of one process on one GPU one after the other (a per-GPU lock), so
+ *     threads may call it concurrently; it still blocks until the tallies are
+ *     on the host. */
+int rtmc_run_noalloc(rtmc_scene *scene, int device, int precision, uint64_t seed,
+                     uint64_t first_photon, uint64_t n_photons, rtmc_tallies *out);
+
 /* Device time of the trace kernel of the calling thread's last rtmc_run, in
  * milliseconds, measured with HIP events on the stream the kernel ran on. */
 double rtmc_last_kernel_ms(const rtmc_scene *scene, int device);

@@ -27,7 +27,7 @@ STATUS = ["Start", "Absorbed", "ReemittedDonor", "ReemittedAcceptor", "InternalC
 
 EXPORTS = ["rtmc_version", "rtmc_last_error", "rtmc_scene_create", "rtmc_scene_destroy",
            "rtmc_run", "rtmc_last_kernel_ms", "rtmc_step_tape", "rtmc_op_intersect",
-           "rtmc_scene_wavelengths", "rtmc_op_crossing"]
+           "rtmc_scene_wavelengths", "rtmc_op_crossing", "rtmc_run_noalloc"]
 
 c_double3 = C.c_double * 3
 c_double9 = C.c_double * 9
@@ -118,6 +118,8 @@ def bind(lib):
     lib.rtmc_run.restype = C.c_int
     lib.rtmc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64,
                              C.POINTER(Tallies)]
+    lib.rtmc_run_noalloc.restype = C.c_int
+    lib.rtmc_run_noalloc.argtypes = lib.rtmc_run.argtypes
     lib.rtmc_last_kernel_ms.restype = C.c_double
     lib.rtmc_last_kernel_ms.argtypes = [C.c_void_p, C.c_int]
     lib.rtmc_step_tape.restype = C.c_int

@@ -543,16 +543,43 @@ struct PerDevice {
 // ---------------------------------------------------------------------------
 // per-GPU state shared by every scene of the process
 // ---------------------------------------------------------------------------
+// Static device memory for rtmc_run_noalloc: the tally block the trace kernel
+// flushes into (at most SCRATCH_TALLY_WORDS 64-bit words) followed by the work
+// counter in a 4 KB piece of its own (tallies and counter are hit by atomics at
+// very different rates and must not share a cache line).  Every GPU the
+// library's code object is loaded on holds its own copy of the array at its own
+// address; host code never uses the array's name as an address, only the
+// pointer hipGetSymbolAddress returned for that GPU.
+constexpr size_t SCRATCH_TALLY_WORDS = 65536;                 // 512 KB
+constexpr size_t SCRATCH_WORK_OFFSET = SCRATCH_TALLY_WORDS;   // in words
+constexpr size_t SCRATCH_WORDS = SCRATCH_TALLY_WORDS + 512;
+static __device__ __align__(256) unsigned long long scratch[SCRATCH_WORDS];
+
 constexpr int MAX_DEVICES = 64;
 namespace {
 struct GpuShared {
     // Held from the first memset of a launch to the end of its copy-back: the
-    // calls of one process on one GPU run one after the other (the calls on one
-    // scene share its tally buffers, stream and events).  Calls on different GPUs do not wait for each other.
+    // calls of one process on one GPU run one after the other (they share that
+    // GPU's scratch array, and the calls on one scene share its tally buffers,
+    // stream and events).  Calls on different GPUs do not wait for each other.
     std::mutex launch_mu;
+    unsigned long long *scratch_ptr = nullptr;  // device address of `scratch` on this GPU
 };
 GpuShared g_gpu[MAX_DEVICES];
+std::mutex g_gpu_setup_mu;
 }  // namespace
+
+// Once per GPU, with that GPU current: the device address of its copy of `scratch`.
+static int setup_gpu_shared(int device)
+{
+    std::lock_guard<std::mutex> lock(g_gpu_setup_mu);
+    if (g_gpu[device].scratch_ptr) return RTMC_OK;
+    void *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return fail(RTMC_EDEVICE, "hipGetSymbolAddress returned a null address for the scratch array on device %d", device);
+    g_gpu[device].scratch_ptr = (unsigned long long *)ptr;
+    return RTMC_OK;
+}
 
 struct rtmc_scene {
     int n_el = 0, n_mat = 0, n_eqe = 0, max_iter = 0;
@@ -1101,6 +1128,10 @@ static int prepare_device(rtmc_scene *s, int device, PerDevice **out)
 
 static int init_device(rtmc_scene *s, int device, PerDevice &p)
 {
+    {
+        const int rc = setup_gpu_shared(device);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&p.ev0));
     HIP_TRY(hipEventCreate(&p.ev1));
@@ -1353,6 +1384,43 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
         if (n_photons) set_last_kernel_ms(s, *pp, ms);
         return RTMC_OK;
     });
+}
+
+RTMC_API int rtmc_run_noalloc(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                                uint64_t n_photons, rtmc_tallies *out)
+{
+    int rc = check_run_arguments(s, precision, first_photon, n_photons, out);
+    if (rc) return rc;
+    DeviceGuard restore_device;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count || device >= MAX_DEVICES)
+        return fail(RTMC_EINVAL, "device %d out of range (%d visible, at most %d supported)", device, count, MAX_DEVICES);
+    HIP_TRY(hipSetDevice(device));
+    PerDevice *pp = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        auto it = s->dev.find(device);  // never inserts
+        if (it != s->dev.end() && it->second.ready) pp = &it->second;
+    }
+    unsigned long long *const base = g_gpu[device].scratch_ptr;
+    if (!pp || !base)
+        return fail(RTMC_EINVAL, "scene is not resident on device %d: rtmc_run (for zero photons, if nothing is to be "
+                                 "traced yet) uploads it, rtmc_run_noalloc never allocates", device);
+    if (pp->tally_words > SCRATCH_TALLY_WORDS)
+        return fail(RTMC_ELIMIT, "the tally block of this scene has %zu words, the static scratch of rtmc_run_noalloc "
+                                 "holds %zu (elements, detectors x wavelength bins): use rtmc_run",
+                    pp->tally_words, SCRATCH_TALLY_WORDS);
+    const uint64_t cap = photons_per_launch_cap();
+    double ms = 0;
+    for (uint64_t done = 0; done < n_photons;) {
+        const uint64_t part = std::min(cap, n_photons - done);
+        rc = launch_and_fold(s, *pp, device, base, base + SCRATCH_WORK_OFFSET, precision, seed, first_photon + done, part, out, &ms);
+        if (rc) return rc;
+        done += part;
+    }
+    if (n_photons) set_last_kernel_ms(s, *pp, ms);
+    return RTMC_OK;
 }
 
 RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device)

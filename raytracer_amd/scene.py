@@ -289,13 +289,16 @@ class Scene:
             pass
 
     def run(self, n_photons, seed=0, first_photon=0, device=0, precision=_abi.F32,
-            tallies=None):
+            tallies=None, noalloc=False):
         """Trace photon ids [first_photon, first_photon + n_photons) and return
-        the tallies as a dict (added to `tallies` = (struct, arrays) if given)."""
+        the tallies as a dict (added to `tallies` = (struct, arrays) if given).
+        `noalloc`: through rtmc_run_noalloc (the scene must be resident on the
+        device already; device tallies in the library's static scratch)."""
         t, arrays = tallies if tallies is not None else new_tallies(self.n_elements)
-        _abi.check(self.lib.rtmc_run(self.handle, int(device), int(precision),
-                                     C.c_uint64(seed), C.c_uint64(first_photon),
-                                     C.c_uint64(n_photons), C.byref(t)), self.lib)
+        entry = self.lib.rtmc_run_noalloc if noalloc else self.lib.rtmc_run
+        _abi.check(entry(self.handle, int(device), int(precision),
+                         C.c_uint64(seed), C.c_uint64(first_photon),
+                         C.c_uint64(n_photons), C.byref(t)), self.lib)
         return tallies_to_dict(t, arrays)
 
     def last_kernel_ms(self, device=0):
