@@ -10,8 +10,13 @@ N > 1 the ranks take disjoint id ranges and the integer tallies are summed
 once with an RCCL all-reduce inside the timed region.
 
 Workload (BASELINE.json configs[1]): the Lumogen Red slab "C2" -- 5 x 5 x 0.3 cm
-slab enclosed by a detector box, 460 nm source, 12 rectangles; K steps of
-2.5e8 photons by default, i.e. 1e9 photons per GPU for the default K = 4.
+slab enclosed by a detector box, 460 nm source, 12 rectangles; one step is
+one call of 1e9 photons per GPU, which is that configuration literally.
+
+Ranks: one process per GPU.  Under `torch.distributed.run` (WORLD_SIZE in the
+environment) this process is one rank.  Started plainly with `--gpus N`, N > 1,
+it starts the N ranks itself -- as child processes, before anything in this
+process has touched a GPU -- waits for them and prints rank 0's line.
 
 Prints one JSON line (rank 0).
 """
@@ -39,19 +44,62 @@ def flops_per_iteration(n_elements):
     return 61 * n_elements + 250
 
 
+def kernel_source_digest():
+    """sha256 over the sources the trace kernel is built from: ties a counter
+    measurement to the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("raytracer_amd/csrc/rtmc_device.h", "raytracer_amd/csrc/rtmc.hip", "include/rtmc.h"):
+        with open(os.path.join(REPO, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def measured_traffic(config, per_step):
-    """HBM bytes per launch from the committed counter passes (profiles/), if
-    they were taken on this workload and launch size; None otherwise."""
+    """HBM bytes per launch from the committed counter passes (profiles/) --
+    only if they were taken on this workload, this launch size and exactly
+    these kernel sources; None (JSON null) otherwise, so that a figure from an
+    older kernel is never reported for a newer one."""
     best = None
     pdir = os.path.join(REPO, "profiles")
+    digest = kernel_source_digest()
     if os.path.isdir(pdir):
         for name in sorted(os.listdir(pdir)):
             if name.endswith("_traffic.json"):
                 with open(os.path.join(pdir, name)) as fh:
                     t = json.load(fh)
-                if t.get("workload") == config and int(t.get("photons_per_launch", 0)) == per_step:
+                if (t.get("workload") == config and int(t.get("photons_per_launch", 0)) == per_step
+                        and t.get("kernel_source_sha256") == digest):
                     best = float(t["hbm_bytes_per_launch"])
     return best
+
+
+def launch_ranks(args, argv):
+    """Start one child process per GPU and relay rank 0's JSON line.  Nothing
+    here imports torch or calls into the HIP runtime: a process that has
+    initialised a GPU must not be the parent of the ranks."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    text = out0.decode("utf-8", "replace")
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+        return max(1, max(abs(c) for c in codes))
+    return 0
 
 
 def main():
@@ -59,19 +107,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--photons-per-step", type=float, default=2.5e8)
+    ap.add_argument("--photons-per-step", type=float, default=1e9)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1.5e8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N ranks on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal only)")
+    ap.add_argument("--dump-tallies", default=None,
+                    help="rank 0 writes the summed tallies of the timed steps to this .npz (tests)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; running %d rank(s)\n"
+                         % (args.gpus, world, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = local_rank if args.device is None else args.device
@@ -125,6 +181,10 @@ def main():
     tall = sc.tallies_to_dict(*block)
 
     out = None
+    if rank == 0 and args.dump_tallies:
+        np.savez(args.dump_tallies, first_photon=first_id(args.warmup) - rank * per_step,
+                 n_requested=per_step * args.steps * world,
+                 **{k: tall[k] for k in list(_abi.TALLY_SCALARS) + list(_abi.TALLY_ARRAYS) + ["spectrum"]})
     if rank == 0:
         total_photons = per_step * args.steps * world
         assert tall["n_photons"] == total_photons, (tall["n_photons"], total_photons)
@@ -167,7 +227,7 @@ def main():
                                  "algorithmic_bytes_per_photon": 96}},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(rt, int(args.cpu_sample), args.seed)
+            out["cpu_baseline"] = cpu_baseline(rt, int(args.cpu_sample), args.seed, args.config)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -175,7 +235,7 @@ def main():
     return out
 
 
-def cpu_baseline(rt, sample, seed):
+def cpu_baseline(rt, sample, seed, config):
     """The float64 CPU checker (oracle/) on a bounded sample of the same workload."""
     from oracle import oracle
     threads = min(16, os.cpu_count() or 1)
@@ -183,10 +243,32 @@ def cpu_baseline(rt, sample, seed):
     t0 = time.perf_counter()
     r = o.run_threads(sample, seed=seed, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "photons/s", "cores": threads, "kind": "port",
-            "sample": "%d photons of the same scene, float64 scalar C restatement of the "
-                      "reference loop, %d host threads, %.1f s" % (sample, threads, dt),
-            "optical_efficiency": float(r["counter"][[2, 3, 4, 5]].sum()) / r["n_photons"]}
+    out = {"value": sample / dt, "unit": "photons/s", "cores": threads, "kind": "port",
+           "sample": "%d photons of the same scene, float64 scalar C restatement of the "
+                     "reference loop, %d host threads, %.1f s" % (sample, threads, dt),
+           "optical_efficiency": float(r["counter"][[2, 3, 4, 5]].sum()) / r["n_photons"]}
+    ref = reference_python_rate(config)
+    if ref:
+        out["reference_python"] = ref
+    return out
+
+
+def reference_python_rate(config):
+    """Photons/s of the reference's own Python loop on one core, from the wall
+    times stored with its seeded runs (tests/golden/ref_tallies.json; measured
+    in the build container, the reference cannot travel to the GPU box)."""
+    path = os.path.join(REPO, "tests", "golden", "ref_tallies.json")
+    try:
+        with open(path) as fh:
+            runs = [r for r in json.load(fh) if r.get("config") == config and r.get("seconds")]
+    except OSError:
+        return None
+    if not runs:
+        return None
+    n, secs = sum(r["n"] for r in runs), sum(r["seconds"] for r in runs)
+    return {"value": n / secs, "unit": "photons/s", "cores": 1, "kind": "reference",
+            "sample": "%d photons in %d seeded runs of the reference's RayTrace.runSimulation "
+                      "(Python, one core, build container), %.0f s" % (n, len(runs), secs)}
 
 
 if __name__ == "__main__":

@@ -68,3 +68,73 @@ def test_allreduce_tallies_gloo_world2(tmp_path):
     assert int(r0["n_photons"]) == 1001 and int(r1["n_photons"]) == 1001
     assert int(r0["n_steps"]) == 7 * 1001 + 1
     assert int(r0["seed"]) == int(r1["seed"])
+
+
+def _run_ranks(world, argv, extra_env=None, timeout=300):
+    """Start `world` processes of tests/dist_worker.py the way a launcher does."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dist_worker.py")] + argv,
+                                      env=env))
+    codes = [p.wait(timeout=timeout) for p in procs]
+    assert codes == [0] * world, codes
+
+
+def test_sharded_runsimulation_equals_single_rank(tmp_path):
+    """RayTrace.runSimulation under two gloo ranks: the ranks take the two
+    halves of the id range (the odd photon goes to rank 0), agree on one seed,
+    and the all-reduced tallies are exactly those of one rank tracing the whole
+    range.  The scene is a stand-in whose tallies are a known function of the
+    photon ids, so the test runs without a GPU and checks the host logic:
+    shard_range, the seed broadcast, allreduce_tallies, _publish."""
+    from raytracer_amd import _abi
+    n = 100001
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    _run_ranks(1, ["C2", str(n), "5", one, "fake"])
+    _run_ranks(2, ["C2", str(n), "5", two, "fake"])
+    a, b = np.load(one), np.load(two)
+    for k in list(_abi.TALLY_SCALARS) + list(_abi.TALLY_ARRAYS) + ["spectrum"]:
+        assert np.array_equal(a[k], b[k]), k
+    assert int(a["n_photons"]) == n and int(a["counter"].sum()) == n
+    r0, r1 = np.load(two + ".rank0.npz"), np.load(two + ".rank1.npz")
+    assert (int(r0["first"]), int(r0["count"])) == (0, 50001)
+    assert (int(r1["first"]), int(r1["count"])) == (50001, 50000)
+    # no seed given: every rank must still use the same one
+    three = str(tmp_path / "three.npz")
+    _run_ranks(2, ["C2", "1000", "-1", three, "fake"])
+    assert int(np.load(three + ".rank0.npz")["seed"]) == int(np.load(three + ".rank1.npz")["seed"])
+
+
+def test_shard_range_covers_every_id_once():
+    from raytracer_amd.distributed import shard_range
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                first, count = shard_range(n, r, world)
+                assert first == nxt and count >= 0
+                nxt = first + count
+            assert nxt == n
+
+
+def test_bench_launcher_starts_the_ranks_before_touching_a_gpu():
+    """`bench.py --gpus N` without WORLD_SIZE must hand the work to N child
+    processes; the parent itself imports neither torch nor the HIP library."""
+    import ast
+    src = open(os.path.join(REPO, "bench.py")).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "launch_ranks")
+    names = {n.names[0].name.split(".")[0] for n in ast.walk(fn) if isinstance(n, (ast.Import, ast.ImportFrom))
+             for _ in [0] if isinstance(n, ast.Import)}
+    names |= {n.module.split(".")[0] for n in ast.walk(fn) if isinstance(n, ast.ImportFrom) and n.module}
+    assert "torch" not in names and "raytracer_amd" not in names, names
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    order = [getattr(n, "lineno") for n in ast.walk(main)
+             if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "launch_ranks"]
+    first_torch = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Import) and n.names[0].name.startswith("torch"))
+    assert order and order[0] < first_torch

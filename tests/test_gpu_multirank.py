@@ -1,0 +1,67 @@
+"""Two ranks on one GPU (gloo): sharded runs equal single-rank runs bit for bit.
+
+The ranks are separate processes started the way a launcher starts them; each
+loads librtmc.so and traces its share of the photon ids on GPU 0, then the
+integer tallies are all-reduced.  (The RCCL path differs only in the transport
+of that one sum.)"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import _abi
+from test_distributed_cpu import REPO, _run_ranks
+
+pytestmark = pytest.mark.gpu
+
+KEYS = list(_abi.TALLY_SCALARS) + list(_abi.TALLY_ARRAYS) + ["spectrum"]
+
+
+def test_two_rank_runsimulation_equals_one_rank(tmp_path):
+    n = 300001
+    one, two = str(tmp_path / "one.npz"), str(tmp_path / "two.npz")
+    _run_ranks(2, ["C3", str(n), "21", two])
+    _run_ranks(1, ["C3", str(n), "21", one])
+    a, b = np.load(one), np.load(two)
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    assert int(b["n_photons"]) == n
+    # and both equal a plain rtmc_run over the id range in this process
+    s = H.raytrace_for("C3").Scene()
+    try:
+        t = s.run(n, seed=21)
+    finally:
+        s.close()
+    for k in KEYS:
+        assert np.array_equal(np.asarray(t[k]), b[k]), k
+
+
+def test_bench_launcher_two_ranks(tmp_path):
+    """`bench.py --gpus 2` with no launcher around it starts two ranks itself
+    and reports them; the tallies it summed over ranks and steps are those of
+    one rtmc_run over the same photon ids."""
+    dump = str(tmp_path / "bench.npz")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--device", "0", "--steps", "2", "--warmup", "1", "--photons-per-step", "250000",
+                          "--no-cpu-baseline", "--dump-tallies", dump],
+                         env=env, stdout=subprocess.PIPE, timeout=300, check=True)
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2
+    assert line["unit"] == "photons/s" and line["value"] > 0
+    d = np.load(dump)
+    first, n = int(d["first_photon"]), int(d["n_requested"])
+    assert int(d["n_photons"]) == n
+    assert (first, n) == (2 * 250000, 2 * 2 * 250000)
+    s = H.raytrace_for("C2").Scene()
+    try:
+        t = s.run(n, seed=1, first_photon=first)
+    finally:
+        s.close()
+    for k in KEYS:
+        assert np.array_equal(np.asarray(t[k]), d[k]), k
