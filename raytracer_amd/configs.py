@@ -204,6 +204,74 @@ def rotated_job(base="C2", axis=(0.3, -0.5, 0.8), angle=0.7, n_photons=10000, **
     return job
 
 
+def strip_job(n_photons=10000, strips=14, sun=False):
+    """C2 with every edge of the slab cut into `strips` detectors side by side
+    (a segmented edge read-out): 4 * strips + 6 detectors, 4 * strips + 8
+    elements.  strips = 1 is C2 itself."""
+    thickness, half = 0.3, 2.5
+    els, props, sizes = _slab_faces(0.0, thickness, half, "LR")
+    els, props, sizes = els[:2], props[:2], sizes[:2]
+    w = 2 * half / strips
+    for axis, sign in ((0, 1), (0, -1), (1, 1), (1, -1)):      # +x, -x, +y, -y as in _slab_faces
+        for k in range(strips):
+            c = -half + (k + 0.5) * w
+            support = [sign * half, c, 0.5 * thickness] if axis == 0 else [c, sign * half, 0.5 * thickness]
+            normal = [-float(sign), 0.0, 0.0] if axis == 0 else [0.0, -float(sign), 0.0]
+            els.append([support, normal])
+            props.append([4, 0, 0, ""])
+            sizes.append([0.5 * w, 0.5 * thickness])
+    e2, p2, s2 = _dump_box(0.0, 0.0, 0.5 * thickness, 4.0, 2.0)
+    els, props, sizes = els + e2, props + p2, sizes + s2
+    photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460, "air", (0.0, 0.0, -1.0))
+    return {
+        "Elements": np.array(els, dtype=np.float64),
+        "ElementProperties": props,
+        "ElementGeometry": [1] * len(els),
+        "ElementSize": [list(x) for x in sizes],
+        "Materials": [copy.deepcopy(AIR_ROW), dye_row("LR")],
+        "Photon": photon,
+    }
+
+
+def flush_detector_job(n_photons=10000):
+    """C2 plus a detector lying flush on the slab's top face (same plane, same
+    footprint), listed after everything else.  In the reference the interface
+    (lower index) wins the tie when a photon arrives, and the detector, now at
+    distance zero, is then not a candidate (RayTrace.py:134): it never counts."""
+    job = slab_job(thickness=0.3, enclosed=True, n_photons=n_photons)
+    job["Elements"] = np.concatenate([job["Elements"], np.array([[[0.0, 0.0, 0.3], [0.0, 0.0, 1.0]]])])
+    job["ElementProperties"] = job["ElementProperties"] + [[4, 0, 0, ""]]
+    job["ElementGeometry"] = job["ElementGeometry"] + [1]
+    job["ElementSize"] = job["ElementSize"] + [[2.5, 2.5]]
+    return job
+
+
+def seam_job(n_photons=10, corner=False):
+    """Strict sources aimed exactly at a seam, with coordinates that are exact in
+    float32 and float64, so that the candidates tie bit for bit.
+    corner=False: a 0.25 cm slab, source at (0, 2, 0.75) along (0, 0.5, -0.5): the
+    top face z = 0.25 (element 1) and the edge detector y = 2.5 (element 4) are
+    both met at line parameter 1.
+    corner=True: a detector box listed z+, z-, x+, x-, y+, y- (the reverse of the
+    order in which the search visits its groups), source at the origin along
+    (1, 1, 0.5): the faces z = 2, x = 4 and y = 4 (elements 0, 2, 4) meet at
+    parameter 4."""
+    if not corner:
+        job = slab_job(thickness=0.25, enclosed=True, n_photons=n_photons, direction=(0.0, 0.5, -0.5))
+        job["Photon"][1] = [0.0, 2.0, 0.75]
+        return job
+    e, p, sz = _dump_box(0.0, 0.0, 0.0, 4.0, 2.0)
+    order = [4, 5, 0, 1, 2, 3]
+    return {
+        "Elements": np.array([e[i] for i in order], dtype=np.float64),
+        "ElementProperties": [p[i] for i in order],
+        "ElementGeometry": [1] * 6,
+        "ElementSize": [sz[i] for i in order],
+        "Materials": [copy.deepcopy(AIR_ROW)],
+        "Photon": _photon(n_photons, (0.0, 0.0, 0.0), STRICT, FIXED_WL, 460, "air", (1.0, 1.0, 0.5)),
+    }
+
+
 def synthetic_am15():
     """Two-column stand-in for the sun table the reference expects in
     `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with

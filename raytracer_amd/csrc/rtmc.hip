@@ -48,6 +48,8 @@ __device__ __forceinline__ HotScene<real> hot_scene(SceneArg<real> sc)
     h.hits = sc.hits; h.elems = sc.elems; h.eqeT = sc.eqeT;
     for (int k = 0; k < 4; k++) h.n_group[k] = sc.n_group[k];
     h.n_wid = (int32_t)sc.lay.n_wid; h.max_iter = sc.max_iter; h.inv_scale = sc.src.inv_scale;
+    h.use_guard = sc.use_guard;
+
     return h;
 }
 
@@ -134,7 +136,9 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     Lds<real> lds = stage_lds(sc, smem, true);
     const HotScene<real> hot = hot_scene(sc);
 
-    LdsTally<real, (FEATURES & FEAT_SPECTRA) != 0> tally;
+    LdsTally<real, (FEATURES & FEAT_SPECTRA) != 0, (FEATURES & FEAT_HBMHIST) != 0> tally;
+    tally.ghist = ((FEATURES & FEAT_HBMHIST) && sc.lay.hist_in_hbm)
+                      ? tl.private_hist + (size_t)blockIdx.x * (sc.lay.n_dump * sc.lay.n_bins) : nullptr;
     tally.acc = lds.acc; tally.hist = lds.hist; tally.fx = lds.fx; tally.bin = lds.bin; tally.wl = sc.wl;
     tally.n_el = sc.n_el; tally.n_bins = (int)sc.lay.n_bins;
     tally.fixed_source = sc.src.wl_mode == 0;
@@ -279,7 +283,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
         else if (i < ACC_SCALARS + 2 * n_el) atomicAdd(&tl.spectral[i - ACC_SCALARS - n_el], v);
         else atomicAdd(&tl.energy_fx[i - ACC_SCALARS - 2 * n_el], v);
     }
-    const int n_hist = (int)(sc.lay.n_dump * sc.lay.n_bins);
+    const int n_hist = sc.lay.hist_in_hbm ? 0 : (int)(sc.lay.n_dump * sc.lay.n_bins);
     for (int i = threadIdx.x; i < n_hist; i += blockDim.x) {
         uint32_t v = lds.hist[i];
         if (v) atomicAdd(&tl.hist[i], (unsigned long long)v);
@@ -322,7 +326,10 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
         p.oldx = real(b.old_point[0][k]); p.oldy = real(b.old_point[1][k]); p.oldz = real(b.old_point[2][k]);
         p.dist = real(b.dist_left[k]);
         p.psi = real(b.psi[k]);
-        p.hitd = M<real>::inf();
+        {   // length of the segment that brought the photon here (the float32 guard distance scales with it)
+            const real sx = p.Lx - p.oldx, sy = p.Ly - p.oldy, sz = p.Lz - p.oldz;
+            p.hitd = M<real>::sqrt(sx * sx + sy * sy + sz * sz);
+        }
         p.wid = b.wid[k]; p.wid0 = b.wid0[k];
         p.mat = b.material[k]; p.status = b.status[k]; p.last_el = b.last_element[k];
         p.flags = (b.was_element[k] != 0 ? F_WAS_EL : 0u) | (b.reflected[k] != 0 ? F_REFLECTED : 0u);
@@ -401,6 +408,17 @@ __global__ void intersect_kernel(const DevScene<real> *scene, uint32_t n, const 
     out[3 * idx] = ok ? (double)(Lx + t * Dx) : nan;
     out[3 * idx + 1] = ok ? (double)(Ly + t * Dy) : nan;
     out[3 * idx + 2] = ok ? (double)(Lz + t * Dz) : nan;
+}
+
+// Adds the workgroups' private detector histograms (HBM) into the tally block.
+__global__ void __launch_bounds__(256)
+sum_private_hist_kernel(const uint32_t *priv, uint32_t n_copies, uint32_t words, unsigned long long *out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    unsigned long long total = 0;
+    for (uint32_t c = 0; c < n_copies; c++) total += priv[(size_t)c * words + i];
+    out[i] += total;
 }
 
 }  // namespace
@@ -508,6 +526,9 @@ uint32_t threshold32(double q)
     return s >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)s;
 }
 
+constexpr int MAX_ELEMENTS = 4096;  // beyond what the LDS holds; the real limit is the size of the LDS image
+constexpr size_t MAX_FRAMES = 64;  // orthonormal frames besides which rectangles take the general test
+
 template <typename real>
 struct DeviceImage {
     std::vector<DevElem<real>> elems;
@@ -532,6 +553,8 @@ struct PerDevice {
     unsigned long long *tallies = nullptr;  // scalars | bounce | spectral | energy | hist
     unsigned long long *work = nullptr;
     unsigned long long *host_tallies = nullptr;  // pinned host copy of `tallies`, filled after every launch
+    uint32_t *private_hist = nullptr;            // per-workgroup detector histograms of scenes that count in HBM
+    size_t private_hist_copies = 0;
     size_t tally_words = 0;
     double last_ms = 0;
     int max_blocks32 = 0, max_blocks64 = 0, n_cu = 0;
@@ -588,11 +611,14 @@ struct rtmc_scene {
     bool has_area = false;          // the source spreads its launch points: the kernel with every feature is used
     bool has_spectra = false;       // spectrum source or a detector with an efficiency table
     bool has_back = false;          // some medium's acceptor can hand the excitation back to its donor
+    bool has_frames = false;        // some rectangle is tested in a frame other than the world's
+    bool has_coplanar = false;      // two elements overlap in one plane: the float32 kernels keep a guard distance
+    bool hist_in_hbm = false;       // detectors x bins too large for the LDS in some precision
     int features() const
     {
-        if (has_area) return FEAT_ALL;
-        return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES : 0) | (has_spectra ? FEAT_SPECTRA : 0) |
-               (has_back ? FEAT_BACK : 0);
+        if (has_area || has_coplanar || hist_in_hbm) return FEAT_ALL;
+        return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES | FEAT_FRAMES : 0) |
+               (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0);
     }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
@@ -674,37 +700,66 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.n2v = (real)d->materials[e.material2].n;
         o.slots = (mat_abs_slot[e.material1] + 1) | ((mat_abs_slot[e.material2] + 1) << 16);
     }
-    // nearest-hit table: axis-aligned rectangles grouped by axis, then the rest
-    auto axis_of = [](const double *v) {  // index of the only non-zero component if it is +-1
-        int k = -1;
-        for (int j = 0; j < 3; j++) {
-            if (v[j] == 0.0) continue;
-            if (k >= 0 || std::fabs(v[j]) != 1.0) return -1;
-            k = j;
+    // nearest-hit table (layout: nearest_valid_hit).  A rectangle whose normal and
+    // in-plane axes are mutually perpendicular joins the frame whose axes they
+    // are (up to order and sign); the world frame is frame 0 and is matched exactly.
+    struct Frame { double r[3][3]; std::vector<HitRec<real>> group[3]; };
+    std::vector<Frame> frames(1);
+    for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) frames[0].r[a][c] = a == c ? 1.0 : 0.0;
+    std::vector<HitRec<real>> general;
+    auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    // row of `f` that v is (plus or minus); -1 if none.  Frame 0 wants the exact unit vector.
+    auto row_of = [&](const Frame &f, const double *v, bool exact) {
+        for (int a = 0; a < 3; a++) {
+            const double c = std::fabs(dot3(f.r[a], v));
+            double off = 0;
+            for (int j = 0; j < 3; j++) off = std::max(off, std::fabs(std::fabs(v[j]) - std::fabs(f.r[a][j])));
+            if (exact ? (c == 1.0 && off == 0.0) : (std::fabs(c - 1.0) <= 1e-12 && off <= 1e-12)) return a;
         }
-        return k;
+        return -1;
     };
-    img.hits.clear();
-    for (int group = 0; group < 4; group++) {
-        std::vector<HitRec<real>> recs;
-        for (int i = 0; i < n_el; i++) {
-            const rtmc_element &e = d->elements[i];
-            const int kn = axis_of(e.normal), k1 = axis_of(e.e1), k2 = axis_of(e.e2);
-            const bool aligned = e.geometry == RTMC_GEOM_RECTANGLE && kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 &&
-                                 kn != k2 && k1 != k2;
-            if ((aligned ? kn : 3) != group) continue;
-            HitRec<real> h;
-            memset(&h, 0, sizeof h);
-            h.index = i;
-            if (aligned) {
+    for (int i = 0; i < n_el; i++) {
+        const rtmc_element &e = d->elements[i];
+        HitRec<real> h;
+        memset(&h, 0, sizeof h);
+        h.index = i;
+        bool placed = false;
+        const bool orthonormal = e.geometry == RTMC_GEOM_RECTANGLE &&
+                                 std::fabs(dot3(e.normal, e.normal) - 1) <= 1e-12 && std::fabs(dot3(e.e1, e.e1) - 1) <= 1e-12 &&
+                                 std::fabs(dot3(e.e2, e.e2) - 1) <= 1e-12 && std::fabs(dot3(e.normal, e.e1)) <= 1e-12 &&
+                                 std::fabs(dot3(e.normal, e.e2)) <= 1e-12 && std::fabs(dot3(e.e1, e.e2)) <= 1e-12;
+        if (orthonormal) {
+            size_t fi = 0;
+            int kn = -1, k1 = -1, k2 = -1;
+            for (; fi < frames.size(); fi++) {
+                kn = row_of(frames[fi], e.normal, fi == 0);
+                k1 = row_of(frames[fi], e.e1, fi == 0);
+                k2 = row_of(frames[fi], e.e2, fi == 0);
+                if (kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2) break;
+            }
+            if (fi == frames.size() && frames.size() < MAX_FRAMES) {
+                Frame f;
+                for (int c = 0; c < 3; c++) { f.r[0][c] = e.e1[c]; f.r[1][c] = e.e2[c]; f.r[2][c] = e.normal[c]; }
+                frames.push_back(f);
+                k1 = 0; k2 = 1; kn = 2;
+            }
+            if (fi < frames.size()) {
+                const Frame &f = frames[fi];
                 const int ai = (kn + 1) % 3, aj = (kn + 2) % 3;
-                h.p0 = (real)e.support[kn];
-                h.ci = (real)e.support[ai]; h.cj = (real)e.support[aj];
+                // frame 0: the coordinate itself, so that an axis-aligned scene is described exactly
+                auto coord = [&](int a) { return fi == 0 ? e.support[a] : dot3(f.r[a], e.support); };
+                h.p0 = (real)coord(kn);
+                h.ci = (real)coord(ai); h.cj = (real)coord(aj);
                 h.hi = (real)(k1 == ai ? e.half1 : e.half2);
                 h.hj = (real)(k1 == ai ? e.half2 : e.half1);
+                frames[fi].group[kn].push_back(h);
+                placed = true;
             }
-            recs.push_back(h);
         }
+        if (!placed) general.push_back(h);
+    }
+    auto pad = [](std::vector<HitRec<real>> &recs) {
         while (recs.size() % HIT_CHUNK) {  // padding that no ray can hit
             HitRec<real> h;
             memset(&h, 0, sizeof h);
@@ -712,14 +767,39 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
             h.index = -1;
             recs.push_back(h);
         }
-        img.n_group[group] = (int)(recs.size() / HIT_CHUNK);
+    };
+    auto emit = [&](const std::vector<HitRec<real>> &recs) {
         for (size_t c = 0; c < recs.size(); c += HIT_CHUNK) {
             HitChunk<real> ch;
             memset(&ch, 0, sizeof ch);
             for (int k = 0; k < HIT_CHUNK; k++) ch.r[k] = recs[c + k];
             img.hits.push_back(ch);
         }
+    };
+    img.hits.clear();
+    int extra_frames = 0;
+    for (size_t fi = 0; fi < frames.size(); fi++) {
+        Frame &f = frames[fi];
+        for (int k = 0; k < 3; k++) pad(f.group[k]);
+        if (fi == 0) {
+            for (int k = 0; k < 3; k++) img.n_group[k] = (int)(f.group[k].size() / HIT_CHUNK);
+        } else {
+            static_assert(sizeof(FrameHdr<real>) == sizeof(HitChunk<real>), "header = one chunk");
+            FrameHdr<real> hdr;
+            memset(&hdr, 0, sizeof hdr);
+            for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 3; c++) hdr.R[3 * a + c] = (real)f.r[a][c];
+            for (int k = 0; k < 3; k++) hdr.n[k] = (int)(f.group[k].size() / HIT_CHUNK);
+            HitChunk<real> raw;
+            memcpy(&raw, &hdr, sizeof raw);
+            img.hits.push_back(raw);
+            extra_frames++;
+        }
+        for (int k = 0; k < 3; k++) emit(f.group[k]);
     }
+    pad(general);
+    emit(general);
+    img.n_group[3] = (int)(general.size() / HIT_CHUNK) | (extra_frames << 16);
     std::vector<DevMat<real>> mats(n_mat);
     int n_slots = 0;
     for (int i = 0; i < n_mat; i++) {
@@ -824,7 +904,13 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.n_dump = (uint32_t)n_dump;
     const size_t n_acc = ACC_SCALARS + 3 * (size_t)n_el;
     lay.hist = (uint32_t)(off + 8 * n_acc);
-    lay.total = (uint32_t)align(lay.hist + 4 * (size_t)std::max(1, n_dump * n_bins));
+    // The detector histogram (detectors x bins, 4 bytes each) stays in LDS while a workgroup of the
+    // largest size still fits; beyond that it is counted in HBM
+    size_t hist_limit = 160 * 1024;
+    if (const char *e = getenv("RTMC_LDS_HIST_LIMIT")) hist_limit = (size_t)strtoull(e, nullptr, 10);  // experiments
+    const size_t with_hist = align(lay.hist + 4 * (size_t)std::max(1, n_dump * n_bins));
+    lay.hist_in_hbm = with_hist > hist_limit ? 1u : 0u;
+    lay.total = (uint32_t)(lay.hist_in_hbm ? align(lay.hist + 16) : with_hist);
     img.lds.assign(off, 0);
     if (n_el) memcpy(img.lds.data() + lay.elems, img.elems.data(), sizeof(DevElem<real>) * n_el);
     if (n_mat) memcpy(img.lds.data() + lay.mats, mats.data(), sizeof(DevMat<real>) * n_mat);
@@ -854,6 +940,52 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.cdf_off = cdf_off[src_cdf]; o.cdf_len = (int)cdfs[src_cdf].size();
         o.guide_off = src_cdf * (GUIDE_BUCKETS + 1);
     }
+}
+
+// Do two flat elements lie in one plane and overlap there?  (Rectangles that
+// only share an edge do not count: a photon meets the seam with probability
+// zero.)  Footprints are compared through their bounding circles and, for two
+// rectangles, through the separating-axis test on their in-plane axes.
+bool coplanar_overlap(const rtmc_scene_desc *d)
+{
+    auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto flat = [](const rtmc_element &e) { return e.geometry != RTMC_GEOM_CYLINDER; };
+    auto radius = [&](const rtmc_element &e) {
+        if (e.geometry == RTMC_GEOM_RECTANGLE) return std::sqrt(e.half1 * e.half1 + e.half2 * e.half2);
+        if (e.geometry == RTMC_GEOM_CIRCLE) return e.half1;
+        double r = 0;  // triangle: support is the centroid
+        for (const double *c : {e.e1, e.e2, e.vertex3}) {
+            double v[3] = {c[0] - e.support[0], c[1] - e.support[1], c[2] - e.support[2]};
+            r = std::max(r, std::sqrt(dot(v, v)));
+        }
+        return r;
+    };
+    for (int i = 0; i < d->n_elements; i++) {
+        const rtmc_element &a = d->elements[i];
+        if (!flat(a)) continue;
+        for (int j = i + 1; j < d->n_elements; j++) {
+            const rtmc_element &b = d->elements[j];
+            if (!flat(b)) continue;
+            const double scale = 1.0 + std::fabs(dot(a.normal, a.support));
+            if (std::fabs(std::fabs(dot(a.normal, b.normal)) - 1.0) > 1e-9) continue;           // not parallel
+            double gap[3] = {b.support[0] - a.support[0], b.support[1] - a.support[1], b.support[2] - a.support[2]};
+            if (std::fabs(dot(a.normal, gap)) > 1e-9 * scale) continue;                           // different planes
+            const double ra = radius(a), rb = radius(b), tol = 1e-9 * (ra + rb + scale);
+            if (std::sqrt(dot(gap, gap)) >= ra + rb - tol) continue;                              // far apart
+            if (a.geometry == RTMC_GEOM_RECTANGLE && b.geometry == RTMC_GEOM_RECTANGLE) {
+                bool separated = false;
+                const double *axes[4] = {a.e1, a.e2, b.e1, b.e2};
+                for (const double *ax : axes) {
+                    const double reach_a = a.half1 * std::fabs(dot(ax, a.e1)) + a.half2 * std::fabs(dot(ax, a.e2));
+                    const double reach_b = b.half1 * std::fabs(dot(ax, b.e1)) + b.half2 * std::fabs(dot(ax, b.e2));
+                    if (std::fabs(dot(ax, gap)) >= reach_a + reach_b - tol) separated = true;
+                }
+                if (separated) continue;
+            }
+            return true;
+        }
+    }
+    return false;
 }
 
 int get_table(const rtmc_scene_desc *d, rtmc_table ref, HostTable &t, const char *what)
@@ -887,7 +1019,8 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
 {
     if (d->abi_version != RTMC_ABI_VERSION)
         return fail(RTMC_EINVAL, "description has ABI version %d, library %d", d->abi_version, RTMC_ABI_VERSION);
-    if (d->n_elements < 1 || d->n_elements > 255) return fail(RTMC_ELIMIT, "1..255 elements supported, got %d", d->n_elements);
+    if (d->n_elements < 1 || d->n_elements > MAX_ELEMENTS)
+        return fail(RTMC_ELIMIT, "1..%d elements supported, got %d", MAX_ELEMENTS, d->n_elements);
     if (d->n_tables < 0 || d->n_tables > 254) return fail(RTMC_ELIMIT, "0..254 detection tables supported, got %d", d->n_tables);
     if (d->n_tables > 0 && !d->tables) return fail(RTMC_EINVAL, "null detection table array");
     if (d->table_data_len < 0 || (d->table_data_len > 0 && !d->table_data)) return fail(RTMC_EINVAL, "null or negative table data");
@@ -989,6 +1122,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     for (int i = 0; i < d->n_elements; i++)
         if (d->elements[i].type == RTMC_TYPE_DUMP && d->elements[i].eqe_table >= 0) s->has_spectra = true;
     s->elements.assign(d->elements, d->elements + d->n_elements);
+    s->has_coplanar = coplanar_overlap(d);
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
     for (int i = 0; i < s->n_el; i++) s->el_eqe[i] = d->elements[i].type == RTMC_TYPE_DUMP ? d->elements[i].eqe_table : -1;
@@ -1029,6 +1163,8 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img32);
     build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
+    s->has_frames = (s->img32.n_group[3] >> 16) != 0;
+    s->hist_in_hbm = s->img32.lay.hist_in_hbm || s->img64.lay.hist_in_hbm;
     if (s->img32.lay.total > 160 * 1024) {
         size_t need = s->img32.lay.total;
         return fail(RTMC_ELIMIT, "scene tables need %zu bytes of LDS, 163840 available", need);
@@ -1042,6 +1178,7 @@ static void free_device(PerDevice &p)
     if (p.ro_block) (void)hipFree(p.ro_block);
     if (p.rw_block) (void)hipFree(p.rw_block);
     if (p.host_tallies) (void)hipHostFree(p.host_tallies);
+    if (p.private_hist) (void)hipFree(p.private_hist);
     if (p.ev0) (void)hipEventDestroy(p.ev0);
     if (p.ev1) (void)hipEventDestroy(p.ev1);
     if (p.stream) (void)hipStreamDestroy(p.stream);
@@ -1077,17 +1214,19 @@ static int upload_scene_structs(rtmc_scene *s, PerDevice &p);
 template <typename real, int BASE>
 static const void *trace_variant(int features)
 {
-    switch (features & (FEAT_ALIGNED | FEAT_SHAPES)) {
+    switch (features & (FEAT_ALIGNED | FEAT_SHAPES | FEAT_FRAMES)) {
     case 0: return (const void *)trace_kernel<real, BASE | 0>;
-    case 1: return (const void *)trace_kernel<real, BASE | 1>;
-    case 2: return (const void *)trace_kernel<real, BASE | 2>;
-    default: return (const void *)trace_kernel<real, BASE | 3>;
+    case FEAT_ALIGNED: return (const void *)trace_kernel<real, BASE | FEAT_ALIGNED>;
+    case FEAT_FRAMES: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES>;
+    case FEAT_FRAMES | FEAT_ALIGNED: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES | FEAT_ALIGNED>;
+    case FEAT_FRAMES | FEAT_SHAPES: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES | FEAT_SHAPES>;
+    default: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES | FEAT_SHAPES | FEAT_ALIGNED>;
     }
 }
 template <typename real>
 static const void *trace_function(int features)
 {
-    if (features & FEAT_AREA) return (const void *)trace_kernel<real, FEAT_ALL>;
+    if (features & (FEAT_AREA | FEAT_GUARD | FEAT_HBMHIST)) return (const void *)trace_kernel<real, FEAT_ALL>;
     if constexpr (sizeof(real) == 8) {
         return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);
     } else {
@@ -1194,6 +1333,11 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
         HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace64, TRACE_BLOCK, s->img64.lay.total));
     }
+    if (s->hist_in_hbm) {  // one private histogram per workgroup that can be resident, in either precision
+        p.private_hist_copies = (size_t)p.n_cu * (size_t)std::max(1, std::max(p.max_blocks32, p.max_blocks64));
+        const size_t words = (size_t)std::max(1, s->n_dump) * s->bins_used.size();
+        HIP_TRY(hipMalloc((void **)&p.private_hist, 4 * words * p.private_hist_copies));
+    }
     {
         int rc = upload_scene_structs(s, p);
         if (rc) return rc;
@@ -1227,6 +1371,7 @@ static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, cons
     sc.src = img.src;
     sc.lay = img.lay;
     sc.n_el = s->n_el; sc.n_mat = s->n_mat; sc.max_iter = s->max_iter;
+    sc.use_guard = s->has_coplanar ? 1 : 0;
     return sc;
 }
 
@@ -1275,6 +1420,9 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
     tl.spectral = tl.bounce + s->n_el;
     tl.energy_fx = tl.spectral + s->n_el;
     tl.hist = tl.energy_fx + s->n_el;
+    tl.private_hist = p.private_hist;
+    const bool private_hist = (f32 ? s->img32.lay.hist_in_hbm : s->img64.lay.hist_in_hbm) != 0;
+    const size_t hist_words = (size_t)std::max(1, s->n_dump) * s->bins_used.size();
 
     // enough waves to fill the machine, never more than there are blocks of ids
     uint64_t wanted = (n_photons + 63) / 64;                          // waves
@@ -1295,6 +1443,10 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
 #else
     HIP_TRY(hipMemsetAsync(dev_work, 0, 8, p.stream));
 #endif
+    if (private_hist) {
+        if (grid > p.private_hist_copies) return fail(RTMC_EDEVICE, "more workgroups than private histograms");
+        HIP_TRY(hipMemsetAsync(p.private_hist, 0, 4 * hist_words * grid, p.stream));
+    }
     HIP_TRY(hipEventRecord(p.ev0, p.stream));
     {
         const void *scene_ptr = f32 ? p.scene32 : p.scene64;
@@ -1304,6 +1456,11 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
         HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(block), args, lds_bytes, p.stream));
     }
     HIP_TRY(hipGetLastError());
+    if (private_hist) {
+        hipLaunchKernelGGL(sum_private_hist_kernel, dim3((unsigned)((hist_words + 255) / 256)), dim3(256), 0, p.stream,
+                           (const uint32_t *)p.private_hist, (uint32_t)grid, (uint32_t)hist_words, tl.hist);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(p.ev1, p.stream));
     HIP_TRY(hipMemcpyAsync(p.host_tallies, dev_tallies, 8 * p.tally_words, hipMemcpyDeviceToHost, p.stream));
     HIP_TRY(hipStreamSynchronize(p.stream));

@@ -71,14 +71,25 @@ struct HitRec {
 // float32 chunk come in two scalar loads behind one wait); every axis group is padded to a multiple of two with records that
 // can never be hit (negative half extents).  Four at a time halves the number
 // of waits but keeps 32 SGPRs busy, which the allocator pays for with spills.
-#ifndef RTMC_HIT_CHUNK
-#define RTMC_HIT_CHUNK 2
-#endif
-constexpr int HIT_CHUNK = RTMC_HIT_CHUNK;
+constexpr int HIT_CHUNK = 2;
 template <typename real>
 struct alignas(64) HitChunk {
     HitRec<real> r[HIT_CHUNK];
 };
+
+// A rectangle whose normal and in-plane axes are perpendicular to each other is
+// axis-aligned in *some* orthonormal frame.  Rectangles that share a frame
+// (the faces of a tilted box, a tilted stack of slabs) are tested in that
+// frame's coordinates with the cheap axis test after one rotation of the line
+// per frame and search.  A frame's header sits in the hit table in front of its
+// three groups and has the size of a chunk.
+template <typename real>
+struct alignas(64) FrameHdr {
+    real R[9];     // rows = the frame's axes in world coordinates: x' = R x
+    int32_t n[3];  // chunks in the frame's x' | y' | z' groups
+};
+static_assert(sizeof(FrameHdr<float>) == sizeof(HitChunk<float>) && sizeof(FrameHdr<double>) == sizeof(HitChunk<double>),
+              "a frame header takes the place of one chunk");
 
 // One medium.
 template <typename real>
@@ -134,6 +145,7 @@ struct LdsLayout {
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
+    uint32_t hist_in_hbm;  // the detector histogram does not fit beside the tables: it is counted in HBM
 };
 
 // Accumulators a workgroup keeps in LDS and flushes once:
@@ -143,9 +155,10 @@ enum { ACC_STEPS = 0, ACC_ABS_ONCE, ACC_ABSORPTIONS, ACC_IC, ACC_CAPPED, ACC_LOS
 
 template <typename real>
 struct DevScene {
-    const HitChunk<real> *hits;  // global, wave-uniform reads; grouped x | y | z | general
+    const HitChunk<real> *hits;  // global, wave-uniform reads; layout: see nearest_valid_hit
     const DevElem<real> *elems;  // global copy for wave-uniform reads (general elements)
-    int32_t n_group[4];          // chunks in each of the four groups of `hits`
+    int32_t n_group[4];          // chunks in the world frame's x | y | z groups; [3] = chunks of the
+                                 // general group | number of further frames << 16
     const uint32_t *lds_image;   // elems | mats | abs | cdf, copied to LDS by every workgroup
     const double *wl;            // wavelength of each id
 
@@ -153,6 +166,7 @@ struct DevScene {
     DevSource<real> src;
     LdsLayout lay;
     int32_t n_el, n_mat, max_iter;
+    int32_t use_guard;
 };
 
 struct DevTallies {
@@ -161,6 +175,7 @@ struct DevTallies {
     unsigned long long *spectral;   // n_el
     unsigned long long *energy_fx;  // n_el
     unsigned long long *hist;       // n_dump * n_bins
+    uint32_t *private_hist;         // scenes that count detector hits in HBM: one n_dump * n_bins block per workgroup
 };
 
 // The kernels receive the scene as a pointer to a device-resident DevScene and
@@ -180,6 +195,7 @@ struct HotScene {
     int32_t n_group[4];
     int32_t n_wid, max_iter;
     real inv_scale;
+    int32_t use_guard;  // float32 kernels with FEAT_GUARD: the scene has coplanar overlapping elements
 };
 
 // Code a scene may need beyond rectangles with isotropic dyes; kernels are
@@ -194,7 +210,16 @@ struct HotScene {
 // FEAT_BACK: some medium allows the back transfer acceptor -> donor
 // (MonteCarloFRET.py:187-190), which reopens the pathway choice with a Philox
 // block of its own in a loop.
-enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_BACK = 16, FEAT_ALL = 31 };
+// FEAT_FRAMES: some rectangle lies in a frame other than the world's (the hit
+// table then holds frame headers and the search a loop over them); kernels
+// with FEAT_SHAPES always have it.
+// FEAT_GUARD (float32; only instantiated together with everything else): see guard_distance.
+// FEAT_HBMHIST (only with everything else): detectors x wavelength bins exceed what the LDS
+// can hold beside the tables; every workgroup then counts hits with atomics in a histogram of
+// its own in HBM (one shared histogram is bounded by the rate of atomics on its few hot
+// words: 2e9 photons/s whatever the scene) and a second kernel adds the copies up.
+enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_BACK = 16, FEAT_FRAMES = 32, FEAT_GUARD = 64,
+             FEAT_HBMHIST = 128, FEAT_ALL = 255 };
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -224,8 +249,7 @@ template <> struct M<float> {
     static __device__ __forceinline__ float copysign(float m, float s) { return __builtin_copysignf(m, s); }
     static __device__ __forceinline__ float huge() { return 3.0e38f; }
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
-    static constexpr bool has_self_hit_eps = false;
-    static constexpr float self_hit_eps = 0.0f;
+    static constexpr bool has_self_hit_eps = false;  // the reference's 1e-8 cm is below float32 resolution here
 };
 template <> struct M<double> {
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
@@ -243,8 +267,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
     static __device__ __forceinline__ double huge() { return 1.0e300; }
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
-    static constexpr bool has_self_hit_eps = true;
-    static constexpr double self_hit_eps = 1e-8;  // RayTrace.py:134
+    static constexpr bool has_self_hit_eps = true;   // RayTrace.py:134 taken literally
 };
 
 template <typename real>
@@ -970,116 +993,203 @@ struct Nearest {
     int32_t e; // its element index, -1 if none
 };
 
+// RayTrace.py:134: a candidate replaces the best so far only if it is strictly
+// nearer, so of several elements at exactly the same distance the first one of
+// the scene's list wins.  The search does not visit the elements in list order
+// (it goes group by group), so an equal distance is decided by the index.
+// `guard`: candidates nearer than this are the photon's own position
+// (RayTrace.py:134: 1e-8 in float64; float32 uses a multiple of its resolution
+// at the scene's size).
 template <typename real>
 __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real t, int index, real adm_q,
-                                         bool adm_all, int skip, real dnorm)
+                                         bool adm_all, int skip, real dnorm, real guard)
 {
-    bool ok = inside & ((t * adm_q > real(0)) | adm_all) & (index != skip) &
-              (M<real>::abs(t) < M<real>::abs(best.t));
-    if (M<real>::has_self_hit_eps) ok = ok & (M<real>::abs(t) * dnorm > M<real>::self_hit_eps);
+    const real a = M<real>::abs(t), b = M<real>::abs(best.t);
+    const bool nearer = (a < b) | ((a == b) & (index < best.e));
+    const bool ok = inside & ((t * adm_q > real(0)) | adm_all) & (index != skip) & nearer & (a * dnorm > guard);
     best.t = ok ? t : best.t;
     best.e = ok ? index : best.e;
 }
 
-// The float32 form of `consider` for a rectangle: in-plane offsets di, dj
+// RayTrace.py:134: nothing nearer than 1e-8 cm is a candidate -- that is the
+// photon's own position.  float64 takes the number as it stands.  float32
+// cannot (1e-8 cm is far below its resolution at these coordinates) and rejects
+// the element the photon sits on by index instead.  That leaves one case open:
+// a *different* element whose plane passes through the photon's position (a
+// detector lying flush on the interface just crossed): its line parameter is
+// the rounding residue of the last move, of either sign.  Scenes that contain
+// such elements (the host finds coplanar overlapping pairs) run kernels with
+// GUARD: a photon that sits on an element then accepts no plane within 8 units
+// in the last place of the numbers that went into its last move (its
+// coordinates and the length of the segment), measured perpendicular to the
+// plane for rectangles.  The guard is not free of side effects -- it also
+// hides a genuine next element that close to the photon, which on 2e7 photons
+// moved 400-800 of them to another fate where 50 differ between float32 and
+// float64 anyway -- so scenes without such elements do not use it.
+template <bool GUARD, typename real>
+__device__ __forceinline__ real guard_distance(const Photon<real> &p, bool scene_wants_it)
+{
+    if constexpr (M<real>::has_self_hit_eps) {
+        return real(1e-8);
+    } else if constexpr (GUARD) {  // kernels that hold the code; the scene says whether it applies
+        const float reach = __builtin_fmaxf(__builtin_fmaxf(M<real>::abs(p.Lx), M<real>::abs(p.Ly)), M<real>::abs(p.Lz)) +
+                            __builtin_fminf(p.hitd, 1e30f);  // hitd is infinite after an iteration without a hit
+        return (scene_wants_it && (p.flags & F_WAS_EL)) ? reach * float(8.0 / 16777216.0) : 0.0f;
+    } else {
+        return real(0);
+    }
+}
+
+// Folds the result of one group into the overall best, with the same rule.
+template <typename real>
+__device__ __forceinline__ void merge_nearest(Nearest<real> &best, const Nearest<real> &g)
+{
+    const real a = M<real>::abs(g.t), b = M<real>::abs(best.t);
+    const bool take = (a < b) | ((a == b) & (g.e < best.e));  // "none" is (inf, -1) and never wins a tie
+    best.t = take ? g.t : best.t;
+    best.e = take ? g.e : best.e;
+}
+
+// The float32 test of the two rectangles of one chunk: in-plane offsets di, dj
 // against half extents hi, hj.  The five conditions narrow the execution mask
 // one compare after the other and the two moves then update the running
 // minimum under the narrowed mask: no mask algebra on the scalar unit, which
 // this loop otherwise keeps as busy as the vector unit.  `ta` carries the
-// admissibility test as a sign: t * adm_q + bias, bias > 0 when every
-// candidate is admissible.  A line parallel to the plane gives t = inf or NaN,
-// which fails the comparisons.
-__device__ __forceinline__ void consider_f32(Nearest<float> &best, float t, float di, float hi, float dj, float hj,
-                                             float ta, int index, int skip, unsigned long long saved)
-{
-    asm("v_cmpx_le_f32_e64 vcc, |%[di]|, %[hi]\n\t"
-        "v_cmpx_le_f32_e64 vcc, |%[dj]|, %[hj]\n\t"
-        "v_cmpx_lt_f32_e32 vcc, 0, %[ta]\n\t"
-        "v_cmpx_ne_u32_e32 vcc, %[idx], %[skip]\n\t"
-        "v_cmpx_lt_f32_e64 vcc, |%[t]|, |%[bt]|\n\t"
-        "v_mov_b32_e32 %[bt], %[t]\n\t"
-        "v_mov_b32_e32 %[be], %[idx]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [bt] "+v"(best.t), [be] "+v"(best.e)
-        : [di] "v"(di), [dj] "v"(dj), [hi] "s"(hi), [hj] "s"(hj), [ta] "v"(ta), [idx] "s"(index), [skip] "v"(skip),
-          [t] "v"(t), [sv] "s"(saved)
-        : "vcc");
-}
-
-__device__ __forceinline__ void consider_axis_f32(Nearest<float> &best, const HitRec<float> &r, float inv_dk,
+// admissibility test as a sign: t * adm_q + bias, with bias > 0 when every
+// candidate is admissible and otherwise minus the guard distance in the units of
+// that product, so that a plane the photon lies in (within rounding) offers no
+// candidate.  A line parallel to the plane gives t = inf or NaN, which fails the
+// comparisons.  Within a group the records are in list order and the compare is
+// strict: the first of equal candidates stays.
+// The block saves the execution mask itself, restores it after each record and
+// is volatile: wherever the compiler places it, it leaves the mask as it found it.
+__device__ __forceinline__ void consider_pair_f32(Nearest<float> &best, const HitChunk<float> &ch, float inv_dk,
                                                   float m_lk, float Li, float Di, float Lj, float Dj, float adm_q,
-                                                  float adm_bias, int skip, unsigned long long saved)
+                                                  float adm_bias, int skip)
 {
-    const float t = r.p0 * inv_dk + m_lk;
-    consider_f32(best, t, (Li + t * Di) - r.ci, r.hi, (Lj + t * Dj) - r.cj, r.hj, t * adm_q + adm_bias, r.index, skip,
-                 saved);
+    const float t0 = ch.r[0].p0 * inv_dk + m_lk, t1 = ch.r[1].p0 * inv_dk + m_lk;
+    const float di0 = (Li + t0 * Di) - ch.r[0].ci, dj0 = (Lj + t0 * Dj) - ch.r[0].cj;
+    const float di1 = (Li + t1 * Di) - ch.r[1].ci, dj1 = (Lj + t1 * Dj) - ch.r[1].cj;
+    const float ta0 = t0 * adm_q + adm_bias, ta1 = t1 * adm_q + adm_bias;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[di0]|, %[hi0]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[dj0]|, %[hj0]\n\t"
+                 "v_cmpx_lt_f32_e32 vcc, 0, %[ta0]\n\t"
+                 "v_cmpx_ne_u32_e32 vcc, %[idx0], %[skip]\n\t"
+                 "v_cmpx_lt_f32_e64 vcc, |%[t0]|, |%[bt]|\n\t"
+                 "v_mov_b32_e32 %[bt], %[t0]\n\t"
+                 "v_mov_b32_e32 %[be], %[idx0]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[di1]|, %[hi1]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[dj1]|, %[hj1]\n\t"
+                 "v_cmpx_lt_f32_e32 vcc, 0, %[ta1]\n\t"
+                 "v_cmpx_ne_u32_e32 vcc, %[idx1], %[skip]\n\t"
+                 "v_cmpx_lt_f32_e64 vcc, |%[t1]|, |%[bt]|\n\t"
+                 "v_mov_b32_e32 %[bt], %[t1]\n\t"
+                 "v_mov_b32_e32 %[be], %[idx1]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [bt] "+v"(best.t), [be] "+v"(best.e), [sv] "=&s"(saved)
+                 : [di0] "v"(di0), [dj0] "v"(dj0), [hi0] "s"(ch.r[0].hi), [hj0] "s"(ch.r[0].hj), [ta0] "v"(ta0),
+                   [idx0] "s"(ch.r[0].index), [t0] "v"(t0), [di1] "v"(di1), [dj1] "v"(dj1), [hi1] "s"(ch.r[1].hi),
+                   [hj1] "s"(ch.r[1].hj), [ta1] "v"(ta1), [idx1] "s"(ch.r[1].index), [t1] "v"(t1), [skip] "v"(skip)
+                 : "vcc");
 }
 
-__device__ __forceinline__ void consider_rect_f32(Nearest<float> &best, const DevElem<float> &e, int index, float Lx,
-                                                  float Ly, float Lz, float Dx, float Dy, float Dz, float adm_q,
-                                                  float adm_bias, int skip, unsigned long long saved)
-{
-    const float den = Dx * e.nx + Dy * e.ny + Dz * e.nz;
-    const float num = e.d0 - (Lx * e.nx + Ly * e.ny + Lz * e.nz);
-    const float t = num * M<float>::rcp(den);
-    const float Bx = Lx + t * Dx, By = Ly + t * Dy, Bz = Lz + t * Dz;
-    consider_f32(best, t, Bx * e.ax + By * e.ay + Bz * e.az - e.c1, e.h1, Bx * e.bx + By * e.by + Bz * e.bz - e.c2,
-                 e.h2, t * adm_q + adm_bias, index, skip, saved);
-}
-
-// One group of axis-aligned rectangles, one chunk of records per scalar fetch.
+// One group of rectangles normal to axis k of the current frame, one chunk of
+// records per scalar fetch; the group's nearest candidate is then folded into
+// the overall best.
 template <typename real>
-__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *table, uint32_t &offset, int count,
-                                                real inv_dk, real m_lk, real Li, real Di, real Lj, real Dj,
-                                                real adm_q, bool adm_all, int skip, real dnorm,
-                                                unsigned long long lanes, Nearest<real> &best)
+__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *table, uint32_t &offset, int count, real Lk,
+                                                real Dk, real Li, real Di, real Lj, real Dj, real adm_q,
+                                                bool adm_all, real guard_q, int skip, real dnorm, real guard,
+                                                Nearest<real> &best, bool first = false)
 {
-    [[maybe_unused]] const real adm_bias = adm_all ? real(1) : real(0);  // adm_q is zero when adm_all is set
+    if (count == 0) return;
+    const real inv_dk = M<real>::rcp(Dk), m_lk = -Lk * inv_dk;
+    // adm_q is zero when adm_all is set; guard_q = guard * |adm_q| and a plane at
+    // line parameter t lies |t D_k| away from the photon
+    // (without a guard guard_q is the constant 0 and the product is not computed)
+    [[maybe_unused]] real adm_bias = adm_all ? real(1) : real(0);
+    if (__builtin_constant_p(guard_q) ? guard_q != real(0) : true)
+        adm_bias = adm_all ? real(1) : -(guard_q * M<real>::abs(inv_dk));
+#ifndef RTMC_TIE_MODE
+#define RTMC_TIE_MODE 2
+#endif
+    // (the first group of a search starts from "none" anyway and scans straight into the result)
+    const bool direct = RTMC_TIE_MODE == 0 || (RTMC_TIE_MODE == 2 && first);
+    Nearest<real> g;
+    g.t = direct ? best.t : M<real>::inf();
+    g.e = direct ? best.e : -1;
     const uint32_t end = offset + (uint32_t)count * (uint32_t)sizeof(HitChunk<real>);
     for (; offset != end; offset += (uint32_t)sizeof(HitChunk<real>)) {
         const HitChunk<real> ch = load_uniform_at(table, offset);
+        if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
+            consider_pair_f32(g, ch, inv_dk, m_lk, Li, Di, Lj, Dj, adm_q, adm_bias, skip);
+        } else {
 #pragma unroll
-        for (int k = 0; k < HIT_CHUNK; k++) {
-            if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
-                consider_axis_f32(best, ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, adm_q, adm_bias, skip, lanes);
-            } else {
+            for (int k = 0; k < HIT_CHUNK; k++) {
                 real t;
                 const bool inside = axis_hit(ch.r[k], inv_dk, m_lk, Li, Di, Lj, Dj, t);
-                consider(best, inside, t, ch.r[k].index, adm_q, adm_all, skip, dnorm);
+                consider(g, inside, t, ch.r[k].index, adm_q, adm_all, skip, dnorm, guard);
             }
         }
     }
+    if (direct) best = g;
+    else merge_nearest(best, g);
+}
+
+// The three axis groups of one frame; (L, D) is the line in that frame.
+template <typename real>
+__device__ __forceinline__ void scan_frame(const HitChunk<real> *table, uint32_t &offset, int n0, int n1, int n2,
+                                           real Lx, real Ly, real Lz, real Dx, real Dy, real Dz, real adm_q,
+                                           bool adm_all, real guard_q, int skip, real dnorm, real guard,
+                                           Nearest<real> &best, bool first = false)
+{
+    scan_axis_group(table, offset, n0, Lx, Dx, Ly, Dy, Lz, Dz, adm_q, adm_all, guard_q, skip, dnorm, guard, best, first);
+    scan_axis_group(table, offset, n1, Ly, Dy, Lz, Dz, Lx, Dx, adm_q, adm_all, guard_q, skip, dnorm, guard, best);
+    scan_axis_group(table, offset, n2, Lz, Dz, Lx, Dx, Ly, Dy, adm_q, adm_all, guard_q, skip, dnorm, guard, best);
 }
 
 // RayTrace.py:120-154 CheckElementsForCrossingPoint: the nearest element whose
 // point the photon may go to next.  Candidates are ordered by |t| (the line
-// parameter); the distance is |t| |D|.  Admissibility: see set_admissibility.
-// The element the photon sits on is skipped by index; the reference rejects it
-// through its 1e-8 distance test (RayTrace.py:134), which the float64
-// instantiation keeps.  `dnorm` returns |D|.
+// parameter); the distance is |t| |D|; equal candidates: see `consider`.
+// Admissibility: see set_admissibility.  The element the photon sits on is
+// skipped by index, and no element offers a candidate within the guard distance
+// of the photon (the reference's `distance > 1e-8`, RayTrace.py:134; in float32
+// the guard is a multiple of the coordinate resolution and is measured
+// perpendicular to the plane for rectangles).  `dnorm` returns |D|.
+//
+// Table order: the rectangles of the world frame grouped by normal axis x | y | z,
+// then for every further frame a header (rotation, group sizes) and its three
+// groups in the frame's coordinates, then the elements tested on their full record.
 template <int FEATURES, typename real>
 __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> &sc, const Photon<real> &p, real &dnorm)
 {
     constexpr bool SHAPES = (FEATURES & FEAT_SHAPES) != 0;
-    const real inv_x = M<real>::rcp(p.Dx), inv_y = M<real>::rcp(p.Dy), inv_z = M<real>::rcp(p.Dz);
-    const real m_x = -p.Lx * inv_x, m_y = -p.Ly * inv_y, m_z = -p.Lz * inv_z;
     dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
     const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
     const bool adm_all = (p.flags & F_ADM_ALL) != 0u;
+    const real guard = guard_distance<(FEATURES & FEAT_GUARD) != 0>(p, sc.use_guard != 0);
+    const real guard_q = (M<real>::has_self_hit_eps || (FEATURES & FEAT_GUARD)) ? guard * M<real>::abs(p.adm_q) : real(0);
     Nearest<real> nearest;
     nearest.t = M<real>::inf();
     nearest.e = -1;
-    // the execution mask of the whole (wave-uniform) search; the float32 tests
-    // narrow it per record and return to this value
-    const unsigned long long lanes = __builtin_amdgcn_read_exec();
     uint32_t offset = 0;  // bytes into the hit table
-    scan_axis_group(sc.hits, offset, sc.n_group[0], inv_x, m_x, p.Ly, p.Dy, p.Lz, p.Dz, p.adm_q, adm_all, skip, dnorm,
-                    lanes, nearest);
-    scan_axis_group(sc.hits, offset, sc.n_group[1], inv_y, m_y, p.Lz, p.Dz, p.Lx, p.Dx, p.adm_q, adm_all, skip, dnorm,
-                    lanes, nearest);
-    scan_axis_group(sc.hits, offset, sc.n_group[2], inv_z, m_z, p.Lx, p.Dx, p.Ly, p.Dy, p.adm_q, adm_all, skip, dnorm,
-                    lanes, nearest);
-    const uint32_t end = offset + (uint32_t)sc.n_group[3] * (uint32_t)sizeof(HitChunk<real>);
+    scan_frame(sc.hits, offset, sc.n_group[0], sc.n_group[1], sc.n_group[2], p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz,
+               p.adm_q, adm_all, guard_q, skip, dnorm, guard, nearest, true);
+    const int n_general = (FEATURES & FEAT_FRAMES) ? (sc.n_group[3] & 0xFFFF) : sc.n_group[3];
+    for (int frames = (FEATURES & FEAT_FRAMES) ? (sc.n_group[3] >> 16) : 0; frames != 0; frames--) {
+        const FrameHdr<real> f = load_uniform_at(reinterpret_cast<const FrameHdr<real> *>(sc.hits), offset);
+        offset += (uint32_t)sizeof(FrameHdr<real>);
+        const real Lx = f.R[0] * p.Lx + f.R[1] * p.Ly + f.R[2] * p.Lz, Ly = f.R[3] * p.Lx + f.R[4] * p.Ly + f.R[5] * p.Lz,
+                   Lz = f.R[6] * p.Lx + f.R[7] * p.Ly + f.R[8] * p.Lz;
+        const real Dx = f.R[0] * p.Dx + f.R[1] * p.Dy + f.R[2] * p.Dz, Dy = f.R[3] * p.Dx + f.R[4] * p.Dy + f.R[5] * p.Dz,
+                   Dz = f.R[6] * p.Dx + f.R[7] * p.Dy + f.R[8] * p.Dz;
+        scan_frame(sc.hits, offset, f.n[0], f.n[1], f.n[2], Lx, Ly, Lz, Dx, Dy, Dz, p.adm_q, adm_all, guard_q, skip,
+                   dnorm, guard, nearest);
+    }
+    const uint32_t end = offset + (uint32_t)n_general * (uint32_t)sizeof(HitChunk<real>);
     for (; offset != end; offset += (uint32_t)sizeof(HitChunk<real>)) {
         const HitChunk<real> ch = load_uniform_at(sc.hits, offset);
 #pragma unroll
@@ -1087,18 +1197,15 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
             const int index = ch.r[k].index;
             if (index < 0) continue;  // padding
             real t;
+            const DevElem<real> e = load_uniform(sc.elems + index);
             if (SHAPES) {
-                const DevElem<real> e = load_uniform(sc.elems + index);
                 const bool wall = (e.type >> 8) == RTMC_GEOM_CYLINDER;  // may be met again right away
                 const bool inside = shape_hit(e, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, (p.flags & F_WAS_EL) != 0u,
                                               index == skip, dnorm, t);
-                consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm);
-            } else if constexpr (sizeof(real) == 4 && !M<real>::has_self_hit_eps) {
-                consider_rect_f32(nearest, load_uniform(sc.elems + index), index, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz,
-                                  p.adm_q, adm_all ? real(1) : real(0), skip, lanes);
-            } else {
-                const bool inside = rect_hit(load_uniform(sc.elems + index), p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
-                consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm);
+                consider(nearest, inside, t, index, p.adm_q, adm_all, wall ? -1 : skip, dnorm, guard);
+            } else {  // a rectangle whose in-plane axes are not perpendicular
+                const bool inside = rect_hit(e, p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz, t);
+                consider(nearest, inside, t, index, p.adm_q, adm_all, skip, dnorm, guard);
             }
         }
     }
@@ -1108,10 +1215,11 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
 // Tally sinks -----------------------------------------------------------------
 // LdsTally: the trace kernel (workgroup accumulators in LDS, detector
 // histogram in HBM).  NoTally: the step-wise kernel.
-template <typename real, bool SPECTRA>
+template <typename real, bool SPECTRA, bool HBMHIST = false>
 struct LdsTally {
     unsigned long long *acc;
     uint32_t *hist;
+    uint32_t *ghist;  // HBMHIST kernels: this workgroup's histogram in HBM if the scene keeps it there, else null
     const uint32_t *fx;
     const uint16_t *bin;
     const double *wl;
@@ -1140,12 +1248,14 @@ struct LdsTally {
     // per photon and scattered global atomics at that rate would bound the kernel.
     __device__ __forceinline__ void dump(int el, int slot, int wid, int wid0, bool counted)
     {
-        atomicAdd(&hist[slot * n_bins + bin[wid]], 1u);
+        if (HBMHIST && ghist) atomicAdd(&ghist[slot * n_bins + bin[wid]], 1u);
+        else atomicAdd(&hist[slot * n_bins + bin[wid]], 1u);
         unsigned long long e = (!SPECTRA || fixed_source)
             ? (unsigned long long)fx[wid]
             : (unsigned long long)__double2ll_rn(wl[wid0] / wl[wid] * RTMC_ENERGY_FX_SCALE);
         atomicAdd(&acc[ACC_SCALARS + 2 * n_el + el], e);
-        if (counted) atomicAdd(&acc[ACC_SCALARS + n_el + el], 1ull);
+        // (without efficiency tables every photon counts and the host takes the counter itself)
+        if (SPECTRA && counted) atomicAdd(&acc[ACC_SCALARS + n_el + el], 1ull);
     }
 };
 struct NoTally {

@@ -359,9 +359,9 @@ def test_results_do_not_depend_on_batching(scenes):
 
 def test_large_scenes(oracle_mod):
     """102 elements (16 stacked slabs + box): float64 kernels against the
-    checker photon for photon.  252 elements (41 slabs; the library takes up
-    to 255, the float64 tables of this one no longer fit the LDS): float32
-    against the checker.  One slab more is refused with a message."""
+    checker photon for photon.  252 elements (41 slabs): both precisions;
+    408 elements (67 slabs): float32 against the checker.  A scene whose element records exceed the LDS is
+    refused with a message."""
     from raytracer_amd import RayTrace, configs
     n = 40000
     rt = RayTrace.RayTrace(demo_scene=False)
@@ -377,16 +377,27 @@ def test_large_scenes(oracle_mod):
     rt.LoadJob(configs.stacked_job(10, n_slabs=41))
     s = rt.Scene()
     assert s.n_elements == 252
-    with pytest.raises(_abi.RtmcError, match="LDS"):
-        s.run(10, seed=4, precision=_abi.F64)
+    g32 = s.run(n, seed=4)
+    g64 = s.run(n, seed=4, precision=_abi.F64)   # 47 detectors: the histogram is counted in HBM, the rest fits the LDS
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=4, threads=8)
+    assert g32["n_photons"] == n
+    assert int(np.abs(g32["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()) <= n // 2000
+    assert int(np.abs(g64["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()) <= 8
+    s.close()
+    # 408 elements (67 slabs): float32 against the checker
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.stacked_job(10, n_slabs=67))
+    s = rt.Scene()
+    assert s.n_elements == 408
     g32 = s.run(n, seed=4)
     cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=4, threads=8)
     assert g32["n_photons"] == n
     assert int(np.abs(g32["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()) <= n // 2000
     s.close()
+    # the limit is the LDS: 300 slabs (1806 element records) no longer fit
     too_many = RayTrace.RayTrace(demo_scene=False)
-    too_many.LoadJob(configs.stacked_job(10, n_slabs=42))
-    with pytest.raises(_abi.RtmcError, match="elements"):
+    too_many.LoadJob(configs.stacked_job(10, n_slabs=300))
+    with pytest.raises(_abi.RtmcError, match="LDS"):
         too_many.Scene()
 
 

@@ -57,3 +57,20 @@ def test_noalloc_after_another_scene_used_the_scratch():
         _same(ta2, a.run(700, seed=8))
     finally:
         a.close(), b.close()
+
+
+def test_noalloc_refuses_a_tally_block_beyond_the_scratch():
+    """126 detectors x the wavelength bins of a spectrum source exceed the 65536 words of
+    the static scratch: rtmc_run_noalloc says so, rtmc_run traces the scene
+    (its detector histogram then lives in HBM, one copy per workgroup)."""
+    from raytracer_amd import RayTrace, configs
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.strip_job(10, strips=30, sun=True))
+    s = rt.Scene()
+    try:
+        t = s.run(50000, seed=2)
+        assert t["n_photons"] == 50000 and np.array_equal(t["spectrum"].sum(axis=1), t["counter"])
+        with pytest.raises(_abi.RtmcError, match="scratch"):
+            s.run(10, noalloc=True)
+    finally:
+        s.close()

@@ -8,6 +8,8 @@ from raytracer_amd import _abi
 np.set_printoptions(linewidth=200, precision=9)
 name = sys.argv[1]
 prec = _abi.F32 if len(sys.argv) < 3 or sys.argv[2] == "f32" else _abi.F64
+_abi.check = lambda rc, lib=None: None   # keep the trace of a replay that ran out of tape
+import raytracer_amd.scene as _sc
 g = H.load_trace(name)
 rt = H.raytrace_for(name)
 s = rt.Scene()
