@@ -237,6 +237,8 @@ template <> struct M<float> {
     static __device__ __forceinline__ void sincospi(float x, float *s, float *c) { ::sincospif(x, s, c); }
     static __device__ __forceinline__ void sincos(float x, float *s, float *c) { ::sincosf(x, s, c); }
     static __device__ __forceinline__ float acos(float x) { return ::acosf(x); }
+    static __device__ __forceinline__ float asin(float x) { return ::asinf(x); }
+    static __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
     static __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
     // sin/cos of 2 pi x for x in [0, 1): v_sin_f32 / v_cos_f32 take their argument in turns
     static __device__ __forceinline__ void sincos_turns(float x, float *s, float *c)
@@ -261,6 +263,8 @@ template <> struct M<double> {
     static __device__ __forceinline__ void sincospi(double x, double *s, double *c) { ::sincospi(x, s, c); }
     static __device__ __forceinline__ void sincos(double x, double *s, double *c) { ::sincos(x, s, c); }
     static __device__ __forceinline__ double acos(double x) { return ::acos(x); }
+    static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
     static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
     static __device__ __forceinline__ void sincos_turns(double x, double *s, double *c) { ::sincospi(2.0 * x, s, c); }
     static __device__ __forceinline__ double neg_log1m(double u) { return -::log(1.0 - u); }
@@ -1212,6 +1216,49 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
     return nearest;
 }
 
+// The direction updates of PhotonObject.py:150 / :199 and the dot product D.n they and the
+// interface start from.  float32 lets the compiler fuse multiplies and adds.  float64 rounds
+// every operation on its own, and sums a dot product the way numpy does, as the reference's
+// arithmetic and the CPU checker do: whether the cosine of an exactly normal incidence on a
+// tilted plane comes out as 1 or as 1 + 2^-52 decides, through the reference's unnormalised
+// arccos (Elements.py:87), between a 4 % reflectance and a NaN, so the last bit matters here.
+template <typename real>
+__device__ __forceinline__ real dot_as_reference(real ax, real ay, real az, real bx, real by, real bz)
+{
+    if constexpr (M<real>::has_self_hit_eps) {
+#pragma clang fp contract(off)
+        return __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx));
+    } else {
+        return ax * bx + ay * by + az * bz;
+    }
+}
+
+template <typename real>
+__device__ __forceinline__ void refract_direction(Photon<real> &p, real r, real cc, real sgn, real nx, real ny, real nz)
+{
+    if constexpr (M<real>::has_self_hit_eps) {
+#pragma clang fp contract(off)
+        const real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
+        p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
+    } else {
+        const real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
+        p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
+    }
+}
+
+template <typename real>
+__device__ __forceinline__ void reflect_direction(Photon<real> &p, real dn, real nx, real ny, real nz)
+{
+    if constexpr (M<real>::has_self_hit_eps) {
+#pragma clang fp contract(off)
+        const real c2 = real(2) * dn;
+        p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
+    } else {
+        const real c2 = real(2) * dn;
+        p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
+    }
+}
+
 // Tally sinks -----------------------------------------------------------------
 // LdsTally: the trace kernel (workgroup accumulators in LDS, detector
 // histogram in HBM).  NoTally: the step-wise kernel.
@@ -1377,7 +1424,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             }
         }
         // PhotonObject.py:135-139 PrepareExecution
-        const real dn = p.Dx * nx + p.Dy * ny + p.Dz * nz;
+        const real dn = dot_as_reference(p.Dx, p.Dy, p.Dz, nx, ny, nz);
         const real off = p.Lx * nx + p.Ly * ny + p.Lz * nz - d0;  // signed distance of the segment start
         const real sgn = real(sgn_i(-dn));
         const real oDx = p.Dx, oDy = p.Dy, oDz = p.Dz;
@@ -1427,19 +1474,38 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             const int other = from1 ? (info >> 8) & 0xFF : info & 0xFF;
             const int other_slot = (from1 ? (el.slots >> 16) : (el.slots & 0xFFFF)) - 1;
             const real n1 = m.n, n2 = from1 ? el.n2v : el.n1v;
-            const real r = n1 * M<real>::rcp(n2);
+            const real r = M<real>::has_self_hit_eps ? n1 / n2 : n1 * M<real>::rcp(n2);
             const real c = M<real>::abs(dn);  // cos(theta_i) for unit D, as Elements.py:87 takes it
-            // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
-            const real cn = c * M<real>::rcp(dnorm);
-            const bool tir = (n1 > n2) & (cn * cn < real(1) - (n2 * n2) * M<real>::rcp(n1 * n1));
-            if (!tir) {
-                // Elements.py:84-109 Reflectance, with cos/sin taken algebraically
+            bool tir;
+            real R_perp, R_par;
+            if constexpr (M<real>::has_self_hit_eps) {
+                // float64 follows the reference's angles literally: Elements.py:77 normalises the
+                // cosine, Elements.py:87 does not, so a cosine that rounding has lifted above 1
+                // (normal incidence on a tilted plane) makes theta_i, the reflectance and the
+                // comparison `rand() > R` NaN / false: the photon is reflected, here as there
+                const real nn = M<real>::sqrt(nx * nx + ny * ny + nz * nz);
+                const real theta_n = M<real>::acos(c / (dnorm * nn));
+                tir = (n1 > n2) & (M<real>::abs(theta_n) > M<real>::asin(n2 / n1));
+                const real theta_i = M<real>::acos(c);
+                const real theta_t = M<real>::asin((n1 / n2) * M<real>::sin(theta_i));
+                const real ci = M<real>::cos(theta_i), ct = M<real>::cos(theta_t);
+                const real rs = (n1 * ci - n2 * ct) / (n1 * ci + n2 * ct);
+                const real rp = (n2 * ci - n1 * ct) / (n2 * ci + n1 * ct);
+                R_perp = rs * rs; R_par = rp * rp;
+            } else {
+                // Elements.py:75-81: theta_i > arcsin(n2/n1)  <=>  cos^2 < 1 - (n2/n1)^2, with the normalised cosine
+                const real cn = c * M<real>::rcp(dnorm);
+                tir = (n1 > n2) & (cn * cn < real(1) - (n2 * n2) * M<real>::rcp(n1 * n1));
+                // Elements.py:84-109 Reflectance, with cos/sin taken algebraically (the physical
+                // value also where the reference's unnormalised arccos turns NaN)
                 real st2 = r * r * (real(1) - c * c);
                 real ct = M<real>::sqrt(real(1) - st2);
                 real a1 = n1 * c, a2 = n2 * ct, b1 = n2 * c, b2 = n1 * ct;
                 real rs = (a1 - a2) * M<real>::rcp(a1 + a2);
                 real rp = (b1 - b2) * M<real>::rcp(b1 + b2);
-                real R_perp = rs * rs, R_par = rp * rp;
+                R_perp = rs * rs; R_par = rp * rp;
+            }
+            if (!tir) {
                 // Elements.py:93-94 normalises E here; it already is a unit vector (every rotation and
                 // every sampler ends with a normalisation), so only the float64 instantiation repeats it
                 if (M<real>::has_self_hit_eps) normalize3(p.Ex, p.Ey, p.Ez);
@@ -1464,9 +1530,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
                 if (g.uniform(0) > R) {  // Elements.py:57-66 crossing
                     reflect = false;
                     // PhotonObject.py:199 Snell
-                    real cc = -dn;
-                    real k = r * cc - sgn * M<real>::sqrt(real(1) - (r * r) * (real(1) - cc * cc));
-                    p.Dx = r * p.Dx + k * nx; p.Dy = r * p.Dy + k * ny; p.Dz = r * p.Dz + k * nz;
+                    refract_direction(p, r, -dn, sgn, nx, ny, nz);
                     p.mat = other;
                     p.flags &= ~F_REFLECTED;
                     if (other_slot >= 0)  // PhotonObject.py:283-305, with E as Reflectance left it
@@ -1478,8 +1542,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             if (reflect) p.flags |= F_REFLECTED;
         }
         if (reflect) {  // PhotonObject.py:150 (line-based: the negative of the mirror direction)
-            real c2 = real(2) * dn;
-            p.Dx = c2 * nx - p.Dx; p.Dy = c2 * ny - p.Dy; p.Dz = c2 * nz - p.Dz;
+            reflect_direction(p, dn, nx, ny, nz);
             tally.bounce(el_idx);
         }
         // PhotonObject.py:117-129 UpdatePolarization: rotate E about D_new x D_old by -arccos(D_new . D_old),

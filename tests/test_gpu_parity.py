@@ -106,6 +106,7 @@ def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     scale = 5.0
     bad_discrete = 0
     worst = 0.0
+    worst_pos = 0.0   # absolute, cm
     where = None
     for j, (i, k) in enumerate(picks):
         ref = states[i + 1]
@@ -117,6 +118,8 @@ def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
             continue
         for key, denom in (("loc", scale), ("dir", 1.0), ("efield", 1.0)):
             err = np.abs(big[key][:, j] - ref[key][:, k]).max() / denom
+            if key == "loc":
+                worst_pos = max(worst_pos, err * denom)
             if err > worst:
                 worst, where = err, (key, i, k, int(states[i]["last_element"][k]), int(ref["last_element"][k]))
         in_abs = rt.Scene().packed.materials[int(ref["material"][k])].IsAbsorber
@@ -127,6 +130,12 @@ def test_f32_single_iteration_within_1e6(scenes, oracle_mod, name):
     # on the curved wall of C8 the normal is computed from the hit point and
     # inherits its rounding divided by the radius (0.5 cm): 2e-6 there
     assert worst < (2e-6 if name == "C8" else 1e-6), (worst, where)
+    # Positions in absolute terms: float32 resolves 4.8e-7 cm at the box walls (4 cm), so a point
+    # is off by at most a few of those -- measured 2.8e-7 cm in C1 (2.3e-5 of its 0.012 cm film)
+    # and 3.5e-7 ... 2.0e-6 cm in the 0.3 cm slabs (7e-6 of the thickness or less).
+    thinnest = 0.012 if name == "C1" else 0.3
+    assert worst_pos <= 3.0e-6 and worst_pos / thinnest <= 5.0e-5, (worst_pos, worst_pos / thinnest)
+    print("%s: worst position error %.2e cm = %.1e of the slab thickness" % (name, worst_pos, worst_pos / thinnest))
 
 
 @pytest.mark.parametrize("name", ["C2", "C4", "C8"])
@@ -240,13 +249,10 @@ def test_philox_f64_matches_checker_photon_for_photon(scenes, oracle_mod, name):
     for key in ("n_steps", "n_absorbed_once", "n_absorptions", "n_internal_converted", "n_dumped",
                 "n_capped", "n_stale_steps"):
         moved += abs(int(gpu[key]) - int(cpu[key]))
-    # C2r: every photon meets the tilted slab at exactly normal incidence.  The reference takes
-    # arccos(-D.n) of unnormalised vectors (Elements.py:87); when rounding lifts |D.n| above 1
-    # that is NaN, the reflectance is NaN and `rand() > R` is false, so the photon is reflected
-    # (and then again at every later normal incidence).  The checker reproduces this, the
-    # kernels use the physical reflectance; the photons that cross the slab unabsorbed and
-    # are reflected at its far face (1 in 2e4) therefore differ.
-    slack = 8 if name != "C2r" else n // 1000
+    # (C2r: every photon meets the tilted slab at exactly normal incidence, where the reference's
+    # arccos of an unnormalised cosine (Elements.py:87) turns NaN when rounding lifts it above 1
+    # and the photon is reflected; the checker and the float64 kernels both follow that.)
+    slack = 8
     assert moved <= slack, moved
     # detector spectra: same photons in the same 1-nm bins
     assert np.abs(gpu["spectrum"].astype(np.int64) - cpu["spectrum"].astype(np.int64)).sum() <= slack
@@ -264,7 +270,10 @@ def test_f32_follows_f64_photon_for_photon(scenes, name):
     b = s.run(n, seed=17, precision=_abi.F64)
     moved = int(np.abs(a["counter"].astype(np.int64) - b["counter"].astype(np.int64)).sum())
     moved += abs(int(a["n_internal_converted"]) - int(b["n_internal_converted"]))
-    assert moved <= n // 50000, moved
+    # C2r: float64 reproduces the reference's NaN reflectance at exactly normal incidence on a
+    # tilted plane (every photon that crosses the slab unabsorbed, 1 in 2e4, is reflected at the
+    # far face instead of leaving with 96 %); float32 deliberately keeps the physical value
+    assert moved <= (n // 50000 if name != "C2r" else n // 5000), moved   # a moved photon changes two counters
     # a photon that is trapped (between the mirrors of C4, in the rod of C8)
     # until the iteration cap in one precision and gets out earlier in the
     # other shifts the total by up to 1e4
