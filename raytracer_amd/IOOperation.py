@@ -43,6 +43,8 @@ class LoadSaveRT:
         self.ElementSize = copy.deepcopy(job["ElementSize"])
         self.Materials = copy.deepcopy(job["Materials"])
         self.PhArray = copy.deepcopy(job["Photon"])
+        # not one of the six files: a sun table handed over with an in-memory job (configs.py)
+        self.SunTable = job.get("SunTable") if isinstance(job, dict) else None
 
     def ParsePath(self, Path):
         """Read a job folder and rebuild the tracer's scene from it
@@ -82,6 +84,8 @@ class LoadSaveRT:
                                   StartingMaterial=rti.MaterialDict[ph[5]],
                                   RespectPolarization=ph[7], StartingLocation=ph[1],
                                   ScaleFactor=ph[8] if len(ph) == 9 else 1.0)
+        rti.Photon.SunTable = getattr(self, "SunTable", None)
+        rti.Photon.SunTableFolder = self.ActivePath or None
         rti.lineclr = rti.Photon.StartingMaterial.color
         rti.CreateOpticalElementList()
 
@@ -93,8 +97,15 @@ class LoadSaveRT:
         folder = os.path.join(self.ActivePath, stamp)
         os.makedirs(folder, exist_ok=True)
         rti = self.RTI
+        # The copy of the job holds the element properties as they were read (material and
+        # detection-spectrum *names*), so that the log folder is itself a job ParsePath can
+        # read; the reference pickles the resolved objects here (IOOperation.py:84-91 replaces
+        # the names in place before :44-45 writes them).
+        as_read = getattr(self, "ElementProperties", None)
+        if as_read is None or len(as_read) != len(rti.ElementProperties):
+            as_read = rti.ElementProperties
         prt.dump_job(folder, {"Elements": rti.Elements,
-                              "ElementProperties": rti.ElementProperties,
+                              "ElementProperties": as_read,
                               "ElementGeometry": rti.ElementGeometry,
                               "ElementSize": rti.ElementSize,
                               "Materials": self.Materials, "Photon": rti.PhArray})

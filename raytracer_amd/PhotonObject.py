@@ -38,6 +38,10 @@ class Photon:
         # StartingLocation; None: point source.  The reference has this as
         # commented-out lines with fixed sizes (PhotonObject.py:74-84).
         self.LaunchArea = LaunchArea
+        # Two-column sun table to use instead of the file `AM15.txt`; None: read the file
+        # (set explicitly, e.g. to configs.synthetic_am15(), never substituted silently).
+        self.SunTable = None
+        self.SunTableFolder = None      # a job folder to look for AM15.txt in besides the working directory
         # state attributes of the reference object (PhotonObject.py:21-37)
         self.PointCy = [0, 0, 0]
         self.OperationPlane = [[0, 0, 0], [0, 0, 0]]
@@ -57,8 +61,14 @@ class Photon:
 
     def sun_table(self):
         """Two-column sun spectrum used when the wavelength type is the sun
-        spectrum: `AM15.txt` from the working directory as the reference
-        reads it (PhotonObject.py:41), else the packaged black-body stand-in."""
-        if os.path.isfile("AM15.txt"):
-            return np.loadtxt("AM15.txt")
-        return configs.synthetic_am15()
+        spectrum: `SunTable` if the caller supplied one, else `AM15.txt` from
+        the working directory as the reference reads it (PhotonObject.py:41;
+        the job folder is searched too).  The reference does not distribute
+        that file and fails with IOError without it; so does this."""
+        if self.SunTable is not None:
+            return np.asarray(self.SunTable, dtype=np.float64)
+        for folder in (".", self.SunTableFolder):
+            if folder and os.path.isfile(os.path.join(folder, "AM15.txt")):
+                return np.loadtxt(os.path.join(folder, "AM15.txt"))
+        raise IOError("AM15.txt not found: the sun-spectrum source (%r) reads this two-column table from the "
+                      "working directory; supply the file or set Photon.SunTable" % SUN)

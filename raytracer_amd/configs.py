@@ -100,7 +100,7 @@ def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=Fal
                     fix_dist_r=fix_dist_r)]
     photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460,
                      "air", direction, respect_pol=respect_pol, scale=scale)
-    return {
+    job = {
         "Elements": np.array(els, dtype=np.float64),
         "ElementProperties": props,
         "ElementGeometry": [1] * len(els),
@@ -108,6 +108,9 @@ def slab_job(thickness=0.3, enclosed=True, donor=False, n_photons=10000, sun=Fal
         "Materials": mats,
         "Photon": photon,
     }
+    if sun:     # the reference reads AM15.txt, which it does not ship: these configurations say which table they mean
+        job["SunTable"] = synthetic_am15()
+    return job
 
 
 def stacked_job(n_photons=10000, n_slabs=3):
@@ -223,7 +226,7 @@ def strip_job(n_photons=10000, strips=14, sun=False):
     e2, p2, s2 = _dump_box(0.0, 0.0, 0.5 * thickness, 4.0, 2.0)
     els, props, sizes = els + e2, props + p2, sizes + s2
     photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460, "air", (0.0, 0.0, -1.0))
-    return {
+    job = {
         "Elements": np.array(els, dtype=np.float64),
         "ElementProperties": props,
         "ElementGeometry": [1] * len(els),
@@ -231,6 +234,9 @@ def strip_job(n_photons=10000, strips=14, sun=False):
         "Materials": [copy.deepcopy(AIR_ROW), dye_row("LR")],
         "Photon": photon,
     }
+    if sun:
+        job["SunTable"] = synthetic_am15()
+    return job
 
 
 def flush_detector_job(n_photons=10000):

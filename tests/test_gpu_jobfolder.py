@@ -1,0 +1,188 @@
+"""Job folder -> device -> result files, and the reference's TestPhoton.py constants.
+
+`RayTrace().IOOperator.ParsePath(folder)` + `runSimulation()` is the
+reference's whole user-facing path (RayTracerGui.py:453-458): six `.prt`
+files in, `Logfile.txt` / `DetectorSpectrum<i>.txt` / `AbsorbedPhotons.txt`
+out (IOOperation.py:34-69).  Here the photon loop in between runs on the GPU."""
+import glob
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import RayTrace, _abi, configs, prt
+from raytracer_amd import scene as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _read_log(folder, n_elements):
+    log = np.loadtxt(os.path.join(folder, "Logfile.txt"))
+    assert log.shape == (n_elements, 4)
+    spectra = {}
+    for path in glob.glob(os.path.join(folder, "DetectorSpectrum*.txt")):
+        i = int(os.path.basename(path)[len("DetectorSpectrum"):-4])
+        spectra[i] = np.loadtxt(path)
+    absorbed = float(np.loadtxt(os.path.join(folder, "AbsorbedPhotons.txt")))
+    return log, spectra, absorbed
+
+
+def _check_files_equal_tallies(rt, t, folder):
+    n_el = len(rt.OpticalElements)
+    log, spectra, absorbed = _read_log(folder, n_el)
+    dumps = [i for i, oe in enumerate(rt.OpticalElements) if oe.Type.kind == "Dump"]
+    assert sorted(spectra) == dumps
+    for i in range(n_el):
+        if i in dumps:
+            assert log[i, 0] == t["counter"][i] and log[i, 2] == t["spectral"][i] and log[i, 3] == 0
+            assert log[i, 1] == pytest.approx(t["energy"][i], rel=1e-15, abs=0)
+            assert spectra[i].shape == (3800, 2)
+            assert np.array_equal(spectra[i][:, 0], np.arange(200, 4000))          # Elements.py:143-144
+            assert np.array_equal(spectra[i][:, 1], t["spectrum"][i].astype(np.float64))
+            assert spectra[i][:, 1].sum() == t["counter"][i]
+        else:
+            assert log[i, 3] == t["bounce"][i] and not log[i, :3].any()
+    assert absorbed == t["n_absorbed_once"]
+
+
+def test_job_folder_round_trip_on_the_device(tmp_path):
+    """C9 (donor + acceptor, detectors with an efficiency table, scale factor,
+    fixed transfer distance) written as a job folder, parsed, traced on the
+    GPU and logged: the files hold exactly the tallies of the run, the job copy
+    in the log folder parses back to the same job, and the counts agree with
+    the reference's own seeded runs of this job within 3 sigma."""
+    n = 400000
+    job = configs.make_job("C9", n)
+    folder = str(tmp_path / "job")
+    prt.dump_job(folder, job)
+    rt = RayTrace.RayTrace()
+    rt.IOOperator.ParsePath(folder)
+    assert rt.NumberOfPhotons == n and len(rt.OpticalElements) == 12
+    rt.Seed = 3
+    t = rt.runSimulation()
+    assert t["n_photons"] == n and t is rt.LastTallies
+    out = rt.IOOperator.LastLogFolder
+    assert os.path.dirname(out) == folder
+    _check_files_equal_tallies(rt, t, out)
+    # the element objects carry what the files say (Elements.py:139-144)
+    for i, oe in enumerate(rt.OpticalElements):
+        if oe.Type.kind == "Dump":
+            assert oe.Type.Counter == t["counter"][i] and oe.Type.SpectralCounter == t["spectral"][i]
+            if 2 <= i <= 5:     # the slab's edge detectors have the efficiency table: it bites
+                assert 0 < oe.Type.SpectralCounter < oe.Type.Counter
+            else:
+                assert oe.Type.SpectralCounter == oe.Type.Counter
+    again = prt.load_job(out)
+    assert again["Photon"][0] == n and again["ElementProperties"] == job["ElementProperties"]
+    assert np.array_equal(again["Elements"], job["Elements"])
+    # the reference's runs of the same job
+    runs = H.ref_tallies("C9")
+    n_ref = sum(r["n"] for r in runs)
+    for key, mine in (("counter", t["counter"]), ("spectral", t["spectral"])):
+        ref = np.sum([r[key] for r in runs], axis=0)
+        for i in range(12):
+            p = float(mine[i]) / n
+            sig = max(1.0, (n_ref * p * (1 - p)) ** 0.5) * (1 + n_ref / n) ** 0.5
+            assert abs(ref[i] - p * n_ref) <= 3 * sig + 1, (key, i, ref[i], p * n_ref)
+
+
+def test_shipped_job_files_on_the_device(tmp_path, golden_dir, oracle_mod):
+    """The six job files the reference ships (tests/golden/shipped_job: an open
+    5 x 5 x 0.012 cm film, aligned dyes with order parameter 1e-99, 1000
+    photons at 460 nm).  Its four spectrum files are not distributed with the
+    reference, so the material row gets the Oxacin / Lumogen Red tables in
+    their place; everything else runs as shipped: ParsePath, the trace on the
+    GPU, SaveLog.  Checked against the CPU checker on the same job."""
+    folder = str(tmp_path / "shipped")
+    shutil.copytree(os.path.join(golden_dir, "shipped_job"), folder)
+    rt = RayTrace.RayTrace()
+    with pytest.raises(IOError, match="Coumarin334"):      # as shipped: the reference fails the same way
+        rt.IOOperator.ParsePath(folder)
+    mats = prt.load(os.path.join(folder, "Materials.prt"))
+    assert mats[1][0] == "PVA_PV19" and mats[1][6] is True and mats[1][8] == 1e-99
+    mats[1][16:20] = ["OxacinAbs.txt", "OxacinEm.txt", "LumogenRedAbs.txt", "LumogenRedEm.txt"]
+    prt.dump(mats, os.path.join(folder, "Materials.prt"))
+    rt = RayTrace.RayTrace()
+    rt.IOOperator.ParsePath(folder)
+    assert rt.NumberOfPhotons == 1000 and len(rt.OpticalElements) == 6
+    assert [oe.Type.kind for oe in rt.OpticalElements] == ["Interface"] * 2 + ["Dump"] * 4
+    rt.Seed = 5
+    t = rt.runSimulation()
+    assert t["n_photons"] == 1000
+    _check_files_equal_tallies(rt, t, rt.IOOperator.LastLogFolder)
+    # statistics need more than the job's 1000 photons
+    rt.IOOperator.ActivePath = ""            # no log for these
+    rt.NumberOfPhotons = 40000
+    g32 = rt.runSimulation()
+    rt.Precision = _abi.F64
+    g64 = rt.runSimulation()
+    cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(40000, seed=5, threads=8)
+    assert g64["n_photons"] == 40000 and g64["n_lost"] == 0
+    for a, b in ((g64, cpu), (g32, cpu)):
+        for i in range(2, 6):
+            p = float(b["counter"][i]) / 40000
+            assert abs(int(a["counter"][i]) - int(b["counter"][i])) <= 4.5 * (2 * 40000 * p * (1 - p)) ** 0.5 + 3
+        assert abs(int(a["n_capped"]) - int(b["n_capped"])) <= 4.5 * (2 * max(1, int(b["n_capped"]))) ** 0.5 + 3
+
+
+def _mirror_scene():
+    """One mirror in the plane z = 0 in air: the plane the reference's
+    TestPhoton.py reflects on."""
+    job = {
+        "Elements": np.array([[[0.0, 0.0, 0.0], [0.0, 0.0, 1.0]]]),
+        "ElementProperties": [[1]],
+        "ElementGeometry": [1],
+        "ElementSize": [[5.0, 5.0]],
+        "Materials": [configs.copy.deepcopy(configs.AIR_ROW)],
+        "Photon": [7, [0.0, 0.0, 0.1], configs.STRICT, configs.FIXED_WL, 460, "air", [0.0, 0.0, -1.0], True, 1.0],
+    }
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(job)
+    return rt
+
+
+@pytest.mark.parametrize("precision", [_abi.F64, _abi.F32])
+def test_reference_testphoton_constants(oracle_mod, precision):
+    """TestPhoton.py:20-25: a generated photon sits at the job's start point.
+    TestPhoton.py:35-51: from (0, 0, 0.1) along (0, 0, -1) the reflection on the
+    plane z = 0 leaves Location {0, 0, 0} and Direction {0, 0, -1} -- the
+    reference's line-based reflection 2(n.D)n - D, the negative of the mirror
+    direction (PhotonObject.py:150).  TestPhoton.py:55-68: along (1, 1, -1)
+    (not normalised) the photon lands at (0.1, 0.1, 0), which satisfies the
+    reference's assertAlmostEqual(..., 0.0909, 0); the same formula gives the
+    direction (-1, -1, -1).  (That test's own assertion on the direction set
+    belongs to a job folder the reference does not ship.)  One loop iteration
+    through rtmc_step_tape, checked against the constants and the checker."""
+    rt = _mirror_scene()
+    s = rt.Scene()
+    o = oracle_mod.OracleScene.from_raytrace(rt)
+    try:
+        tape = np.array([0.3, -0.2, 0.9] + [0.5] * 4)
+        off = np.array([0, len(tape)], dtype=np.uint64)
+        b = sc.new_photon_batch(1)
+        s.step_tape(b, tape, off, 0, launch=True, precision=precision)      # GeneratePhoton only
+        assert list(b["loc"][:, 0]) == pytest.approx([0.0, 0.0, 0.1], abs=1e-8 if precision == _abi.F32 else 0)
+        assert b["iterations"][0] == 0
+        for direction, loc, out in (([0.0, 0.0, -1.0], [0.0, 0.0, 0.0], [0.0, 0.0, -1.0]),
+                                    ([1.0, 1.0, -1.0], [0.1, 0.1, 0.0], [-1.0, -1.0, -1.0])):
+            def state():
+                st = sc.new_photon_batch(1)
+                st["loc"][:, 0] = st["old_point"][:, 0] = [0.0, 0.0, 0.1]
+                st["dir"][:, 0] = direction
+                st["efield"][:, 0] = np.cross(direction, [0.0, 1.0, 0.0]) / np.linalg.norm(np.cross(direction, [0.0, 1.0, 0.0]))
+                st["wavelength"][:] = st["start_wavelength"][:] = 460.0
+                return st
+            got, ref = state(), state()
+            s.step_tape(got, tape, off, 1, launch=False, precision=precision)
+            o.step_tape(ref, tape, off, 1, launch=False)
+            tol = 1e-15 if precision == _abi.F64 else 2e-7
+            assert np.allclose(got["loc"][:, 0], loc, rtol=0, atol=tol), got["loc"][:, 0]
+            assert np.allclose(got["dir"][:, 0], out, rtol=0, atol=tol), got["dir"][:, 0]
+            assert np.allclose(ref["loc"][:, 0], loc, rtol=0, atol=1e-15) and np.allclose(ref["dir"][:, 0], out, rtol=0, atol=1e-15)
+            assert got["last_element"][0] == 0 and got["reflected"][0] == ref["reflected"][0]
+            assert got["hit_distance"][0] == pytest.approx(0.1 * np.linalg.norm(direction), rel=1e-6)
+            assert round(float(got["loc"][0, 0]), 0) == round(0.09090909, 0)     # the reference's own assertion
+    finally:
+        s.close()
