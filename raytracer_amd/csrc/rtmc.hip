@@ -144,7 +144,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     tally.fixed_source = sc.src.wl_mode == 0;
     tally.lane_steps = 0ull; tally.lane_abs_once = 0u;
 #ifdef RTMC_PROFILE_SECTIONS
-    for (int k = 0; k < 4; k++) tally.prof[k] = 0ull;
+    for (int k = 0; k < tally.N_PROF; k++) { tally.prof[k] = 0ull; tally.prof_n[k] = 0u; }
 #endif
 
     Photon<real> p;
@@ -181,15 +181,17 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             // (a) absorbed photons: donor/acceptor coin and pathway (PhotonObject.py:244,
             //     MonteCarloFRET.py:63-193); one event, a back transfer opens another
             bool emitting = false;
+            tally.stamp_begin();
             if (need == NEED_RETIRE) {
                 if (p.status == RTMC_ST_DUMPED) finish_dumped<(FEATURES & FEAT_SPECTRA) != 0>(hot, lds, p, g, tally);
                 count_fate(p, tally);
                 need = NEED_LAUNCH;
             }
+            tally.stamp(4);
             if (need == NEED_EMIT) {
                 finish_absorbed_move(p, tally);
-                const DevMat<real> &m = lds.mats[p.mat];
-                const DevAbs<real> &a = lds.abs[m.abs_slot * hot.n_wid + p.wid];
+                const DevMat<real> &m = row(lds.mats, p.mat);
+                const DevAbs<real> &a = row(lds.abs, mul24(m.abs_slot, hot.n_wid) + p.wid);
                 const bool in_donor = absorbed_by_donor<ALIGNED>(m, a, p, g);
                 uint32_t v_lambda;
                 const int outcome = fret_decide<(FEATURES & FEAT_BACK) != 0>(m, g, in_donor, (uint32_t)p.iter, v_lambda);
@@ -209,6 +211,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                     emitting = true;
                 }
             }
+            tally.stamp(5);
             // (b) photon ids for the lanes without a photon
             bool launching = false;
             const unsigned long long idle = __ballot(need == NEED_LAUNCH);
@@ -235,19 +238,22 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 }
             }
             if (exhausted && need == NEED_LAUNCH) need = NEED_OFF;
+            tally.stamp(6);
             // (c) one event for both: direction, polarisation, free path / wavelength
             if (launching | emitting) {
                 // an emitting photon's iteration count has already moved on
                 const uint32_t emit_iter = (uint32_t)p.iter - 1u;
                 g.block(launching ? 0u : emit_iter, launching ? BLK_LAUNCH : BLK_EMIT);
+                tally.stamp(7);
                 bool special = false;  // fluorescence of an aligned acceptor
                 if (ALIGNED && emitting)
-                    special = (lds.mats[p.mat].flags & 2) && p.status == RTMC_ST_REEMITTED_ACCEPTOR;
+                    special = (row(lds.mats, p.mat).flags & 2) && p.status == RTMC_ST_REEMITTED_ACCEPTOR;
                 if (special)
-                    renew_emit_aligned(hot, lds, lds.mats[p.mat], p, g, emit_iter);
+                    renew_emit_aligned(hot, lds, row(lds.mats, p.mat), p, g, emit_iter);
                 else
                     renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0, (FEATURES & FEAT_SPECTRA) != 0>(sc, hot, lds, p, g, launching);
                 need = NEED_NONE;
+                tally.stamp(8);
             }
             SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);
         }
@@ -265,7 +271,10 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     if (lane == 0) {  // per-wave totals behind the work counter
         atomicAdd(&work[8], cyc_renew); atomicAdd(&work[9], n_renew); atomicAdd(&work[10], lanes_renew);
         atomicAdd(&work[11], cyc_step); atomicAdd(&work[12], n_step); atomicAdd(&work[13], lanes_step);
-        for (int k = 0; k < 4; k++) atomicAdd(&work[14 + k], tally.prof[k]);
+    }
+    for (int k = 0; k < tally.N_PROF; k++) {
+        atomicAdd(&work[16 + k], tally.prof[k]);
+        atomicAdd(&work[32 + k], (unsigned long long)tally.prof_n[k]);
     }
 #endif
 
@@ -337,7 +346,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
         p.best_t = real(0);
         set_admissibility_forward(p);
         if ((p.flags & F_WAS_EL) && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
-            const DevElem<real> &le = lds.elems[p.last_el];
+            const DevElem<real> &le = row(lds.elems, p.last_el);
             real nx = le.nx, ny = le.ny, nz = le.nz;
             double d0 = (double)le.d0;
             if ((le.type >> 8) == RTMC_GEOM_CYLINDER) {  // the photon sits on the tangent plane of its last operation
@@ -1439,7 +1448,7 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
     std::lock_guard<std::mutex> serial(g_gpu[device].launch_mu);
     HIP_TRY(hipMemsetAsync(dev_tallies, 0, 8 * p.tally_words, p.stream));
 #ifdef RTMC_PROFILE_SECTIONS
-    HIP_TRY(hipMemsetAsync(dev_work, 0, 256, p.stream));
+    HIP_TRY(hipMemsetAsync(dev_work, 0, 512, p.stream));
 #else
     HIP_TRY(hipMemsetAsync(dev_work, 0, 8, p.stream));
 #endif
@@ -1469,16 +1478,27 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
     *kernel_ms += ms;
 #ifdef RTMC_PROFILE_SECTIONS
     {
-        unsigned long long w[18];
+        unsigned long long w[48];
         HIP_TRY(hipMemcpy(w, dev_work, sizeof w, hipMemcpyDeviceToHost));
+        const double total = (double)(w[8] + w[11]);
         fprintf(stderr, "[rtmc] sections: renew %llu passes, %.0f cycles each, %.1f lanes; step %llu passes, %.0f cycles each, %.1f lanes; "
-                        "renew share of wave time %.3f\n",
+                        "renew share of wave time %.3f; lane utilisation %.3f\n",
                 w[9], (double)w[8] / (double)std::max(1ull, w[9]), (double)w[10] / (double)std::max(1ull, w[9]),
                 w[12], (double)w[11] / (double)std::max(1ull, w[12]), (double)w[13] / (double)std::max(1ull, w[12]),
-                (double)w[8] / (double)(w[8] + w[11]));
-        fprintf(stderr, "[rtmc] inside step (cycles per pass, lane 0 of each wave): philox %.0f, search %.0f, absorption check %.0f, operation %.0f\n",
-                (double)w[14] / (double)std::max(1ull, w[12]), (double)w[15] / (double)std::max(1ull, w[12]),
-                (double)w[16] / (double)std::max(1ull, w[12]), (double)w[17] / (double)std::max(1ull, w[12]));
+                (double)w[8] / total,
+                ((double)w[8] * (double)w[10] / (double)std::max(1ull, w[9]) +
+                 (double)w[11] * (double)w[13] / (double)std::max(1ull, w[12])) / (64.0 * total));
+        static const char *names[9] = {"step: philox", "step: search", "step: absorption check", "step: element operation",
+                                       "renew: endings", "renew: pathway + wavelength", "renew: photon ids",
+                                       "renew: philox", "renew: direction, polarisation, free path"};
+        for (int k = 0; k < 9; k++) {
+            // cycles per pass of a lane that took part; lanes per pass; share of all wave time
+            const double per = (double)w[16 + k] / (double)std::max(1ull, w[32 + k]);
+            const double passes = (double)(k < 4 ? w[12] : w[9]);
+            const double lanes = (double)w[32 + k] / std::max(1.0, passes);
+            fprintf(stderr, "[rtmc]   %-42s %6.0f cycles, %4.1f lanes, %4.1f %% of wave time\n", names[k], per, lanes,
+                    100.0 * per * passes / total);
+        }
     }
 #endif
 

@@ -409,6 +409,16 @@ struct Lds {
     uint32_t *hist;
 };
 
+// Rows of the LDS tables are addressed with the 24-bit multiply: it runs at the full vector
+// rate, a 32-bit integer multiply at a quarter of it, and indices and record sizes are far
+// below 2^24.
+__device__ __forceinline__ int mul24(int a, int b) { return (int)__umul24((unsigned)a, (unsigned)b); }
+template <typename T>
+__device__ __forceinline__ const T &row(const T *base, int index)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + __umul24((unsigned)index, (unsigned)sizeof(T)));
+}
+
 // number of thresholds <= v  ==  numpy.searchsorted(cdf, u, side='right')
 __device__ __forceinline__ int cdf_pick(const uint32_t *T, int n, uint32_t v)
 {
@@ -464,11 +474,11 @@ template <bool ALIGNED, typename real>
 __device__ __forceinline__ real free_path(const HotScene<real> &sc, const Lds<real> &lds, int mat, int slot,
                                           Photon<real> &p, real e)
 {
-    const DevAbs<real> &a = lds.abs[slot * sc.n_wid + p.wid];
+    const DevAbs<real> &a = row(lds.abs, mul24(slot, sc.n_wid) + p.wid);
     real b_a = a.b_a;
     if (ALIGNED) {
-        if (lds.mats[mat].flags & 2) {
-            p.psi = orientation_integral(lds.orient[mat], p.Ex, p.Ey, p.Ez);
+        if (row(lds.mats, mat).flags & 2) {
+            p.psi = orientation_integral(row(lds.orient, mat), p.Ex, p.Ey, p.Ez);
             b_a *= p.psi * real(3);
         }
     }
@@ -683,13 +693,13 @@ template <typename real>
 __device__ __forceinline__ void emit_in_reference_order(const HotScene<real> &sc, const Lds<real> &lds,
                                                         Photon<real> &p, Rng<real, true> &g)
 {
-    const DevMat<real> &m = lds.mats[p.mat];
-    const DevAbs<real> &a = lds.abs[m.abs_slot * sc.n_wid + p.wid];
+    const DevMat<real> &m = row(lds.mats, p.mat);
+    const DevAbs<real> &a = row(lds.abs, mul24(m.abs_slot, sc.n_wid) + p.wid);
     bool in_donor = absorbed_by_donor<true>(m, a, p, g);  // PhotonObject.py:244
     uint32_t v_lambda;
     int outcome = fret_decide<true>(m, g, in_donor, 0u, v_lambda);
     if (outcome == 2 && (m.flags & 2)) {  // MonteCarloFRET.py:124-162
-        const DevOrient<real> &o = lds.orient[p.mat];
+        const DevOrient<real> &o = row(lds.orient, p.mat);
         real sx, cx, s_az, c_az, s_phi, c_phi, s_ph = real(0), c_ph = real(1);
         for (;;) {  // RTUtils.py:64-68 rejection sampling of sin^3 on [0, pi]
             M<real>::sincospi(g.uniform(0), &sx, &cx);
@@ -773,7 +783,7 @@ __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<r
     // member in each arm is merged into one store through a selected address, which
     // keeps those members of the photon record in scratch memory.)
     real dist = real(0);
-    if (!launching) dist = free_path<ALIGNED>(hot, lds, p.mat, lds.mats[p.mat].abs_slot, p, g.expo(3));
+    if (!launching) dist = free_path<ALIGNED>(hot, lds, p.mat, row(lds.mats, p.mat).abs_slot, p, g.expo(3));
     if (launching) {
         p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
         p.wid = s.wid_fixed;
@@ -801,7 +811,7 @@ __device__ __forceinline__ void renew_emit_aligned(const HotScene<real> &sc, con
                                                    const DevMat<real> &m, Photon<real> &p, Rng<real, false> &g,
                                                    uint32_t iter)
 {
-    const DevOrient<real> &o = lds.orient[p.mat];
+    const DevOrient<real> &o = row(lds.orient, p.mat);
     const real pi = real(3.141592653589793);
     const real cx = real(2) * M<real>::cos((M<real>::acos(real(2) * g.uniform(0) - real(1)) + real(4) * pi) * real(1.0 / 3.0));
     const real s2 = real(1) - cx * cx;
@@ -1276,9 +1286,26 @@ struct LdsTally {
     unsigned long long lane_steps;
     uint32_t lane_abs_once;
 #ifdef RTMC_PROFILE_SECTIONS
-    unsigned long long prof[4], prof_t;  // cycle stamps inside photon_step (wave-uniform values)
-    __device__ __forceinline__ void stamp_begin() { prof_t = __builtin_readcyclecounter(); }
-    __device__ __forceinline__ void stamp(int k) { unsigned long long t = __builtin_readcyclecounter(); prof[k] += t - prof_t; prof_t = t; }
+    // cycle stamps (diagnostic build only): per lane the cycles and the number of passes of every
+    // stamped interval it took part in; the host divides the sums.  0 Philox, 1 search, 2 absorption
+    // check, 3 element operation (step); 4 endings, 5 pathway + wavelength of absorbed photons,
+    // 6 photon ids, 7 Philox, 8 direction / polarisation / free path (renew block)
+    enum { N_PROF = 9 };
+    unsigned long long prof[N_PROF], prof_t;
+    uint32_t prof_n[N_PROF];
+    __device__ __forceinline__ void stamp_begin()
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        prof_t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void stamp(int k)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+        prof[k] += t - prof_t; prof_n[k]++; prof_t = t;
+    }
 #else
     __device__ __forceinline__ void stamp_begin() {}
     __device__ __forceinline__ void stamp(int) {}
@@ -1295,8 +1322,8 @@ struct LdsTally {
     // per photon and scattered global atomics at that rate would bound the kernel.
     __device__ __forceinline__ void dump(int el, int slot, int wid, int wid0, bool counted)
     {
-        if (HBMHIST && ghist) atomicAdd(&ghist[slot * n_bins + bin[wid]], 1u);
-        else atomicAdd(&hist[slot * n_bins + bin[wid]], 1u);
+        if (HBMHIST && ghist) atomicAdd(&ghist[mul24(slot, n_bins) + bin[wid]], 1u);
+        else atomicAdd(&hist[mul24(slot, n_bins) + bin[wid]], 1u);
         unsigned long long e = (!SPECTRA || fixed_source)
             ? (unsigned long long)fx[wid]
             : (unsigned long long)__double2ll_rn(wl[wid0] / wl[wid] * RTMC_ENERGY_FX_SCALE);
@@ -1345,10 +1372,10 @@ template <bool SPECTRA, typename real, bool TAPE, typename Tally>
 __device__ __forceinline__ void finish_dumped(const HotScene<real> &sc, const Lds<real> &lds, const Photon<real> &p,
                                               Rng<real, TAPE> &g, Tally &tally)
 {
-    const int info = lds.elems[p.last_el].info;
+    const int info = row(lds.elems, p.last_el).info;
     bool counted = true;
     const int eqe = (info & 0xFF) - 1;
-    if (SPECTRA && eqe >= 0) counted = g.u32(0) < sc.eqeT[(size_t)eqe * sc.n_wid + p.wid];
+    if (SPECTRA && eqe >= 0) counted = g.u32(0) < sc.eqeT[mul24(eqe, sc.n_wid) + p.wid];
     tally.dump(p.last_el, info >> 8, p.wid, p.wid0, counted);
 }
 
@@ -1392,7 +1419,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     }
 
     // ---- PhotonObject.py:206-264 CheckForAbsorption -------------------------
-    const DevMat<real> &m = lds.mats[p.mat];
+    const DevMat<real> &m = row(lds.mats, p.mat);
     if (m.flags & 1) {
         if (p.dist > p.hitd) {
             p.dist -= p.hitd;
@@ -1411,7 +1438,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     tally.stamp(2);
     // ---- the element's ExecuteOperation -------------------------------------
     {
-        const DevElem<real> &el = lds.elems[el_idx];  // per-lane gather from LDS
+        const DevElem<real> &el = row(lds.elems, el_idx);  // per-lane gather from LDS
         real nx = el.nx, ny = el.ny, nz = el.nz, d0 = el.d0;
         const int type = el.type & 0xFF, info = el.info;
         if (SHAPES) {
