@@ -131,7 +131,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = local_rank if args.device is None else args.device
-    if world > 1:
+    # a launcher's environment (torch.distributed.run, or launch_ranks above) makes this a rank
+    # even when it is the only one: the process group and the RCCL all-reduce are then exercised
+    grouped = "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    if grouped:
         torch.cuda.set_device(device)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -148,7 +151,7 @@ def main():
     n_el = scene.n_elements
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +176,7 @@ def main():
     distributed.allreduce_tallies(block, device)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -229,7 +232,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, int(args.cpu_sample), args.seed, args.config)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -65,3 +65,32 @@ def test_bench_launcher_two_ranks(tmp_path):
         s.close()
     for k in KEYS:
         assert np.array_equal(np.asarray(t[k]), d[k]), k
+
+
+def test_rccl_path_with_one_rank(tmp_path):
+    """The launch line the driver uses (`python -m torch.distributed.run ...
+    bench.py --gpus N`) with N = 1 and the default backend: the process group
+    is created on RCCL (backend "nccl") and the tally block goes through its
+    all-reduce on the device.  One rank is all a one-GPU box can hold -- RCCL
+    refuses two ranks on one device -- but init, barrier, all-reduce and
+    teardown are the calls N ranks make."""
+    dump = str(tmp_path / "rccl.npz")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29613",
+                          os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--photons-per-step", "300000", "--no-cpu-baseline", "--dump-tallies", dump],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+    d = np.load(dump)
+    s = H.raytrace_for("C2").Scene()
+    try:
+        t = s.run(int(d["n_requested"]), seed=1, first_photon=int(d["first_photon"]))
+    finally:
+        s.close()
+    for k in KEYS:
+        assert np.array_equal(np.asarray(t[k]), d[k]), k
