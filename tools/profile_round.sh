@@ -1,9 +1,19 @@
+# One GPU session of evidence for a round: tools/profile_round.sh r02
+#   bench.py (default arguments), rocprofv3 --kernel-trace --stats of the same command, the --pmc
+#   passes of pmc.sh over one launch of the bench's size, their summary, the traffic file that
+#   bench.py reports as roofline.traffic (stamped with the digest of the kernel sources), and the
+#   cycle stamps of the diagnostic build.  Results under gpurun_out/prof_<round>/; copy into profiles/.
 set -e
+R=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/prof_r01
-timeout -k 10 300 python bench.py > gpurun_out/prof_r01/bench.json 2> gpurun_out/prof_r01/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01/stats -o bench -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_r01/bench_under_rocprof.json 2> gpurun_out/prof_r01/rocprof.err
-bash tools/pmc.sh r01 2.5e8 C2 > gpurun_out/prof_r01/pmc.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/pmc_r01 > gpurun_out/prof_r01/pmc_summary.txt
-ls gpurun_out/prof_r01/stats | head
+O=gpurun_out/prof_$R
+mkdir -p $O
+timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err
+bash tools/pmc.sh $R 1e9 C2 > $O/pmc.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/pmc_$R > $O/pmc_summary.txt
+python3 tools/traffic_json.py $O/pmc_summary.txt 1000000000 C2 > $O/traffic.json
+timeout -k 10 300 python3 tools/sections.py 1e8 C2 C3 C4 C2r C1 2> $O/sections.txt
+find $O/stats -name "*kernel_stats.csv" | head -3
+cat $O/bench.json

@@ -18,6 +18,7 @@ import helpers as H  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100000000
 for name in sys.argv[2:] or ["C2", "C3", "C4", "C2r"]:
     s = H.raytrace_for(name).Scene()
+    print("-- %s: warm-up launch of 1e6 photons (ignore)" % name, file=sys.stderr, flush=True)
     s.run(1000000, seed=3)
     sys.stderr.flush()
     print("== %s, %d photons" % (name, n), file=sys.stderr, flush=True)
