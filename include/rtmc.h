@@ -322,6 +322,53 @@ int rtmc_op_crossing(rtmc_scene *scene, int device, int precision, uint32_t n,
                      const rtmc_photon_soa *photons, int32_t *element, double *distance,
                      double *points);
 
+/* The single operations the reference's Photon and element objects offer to a
+ * script that moves one photon by hand (its TestPhoton.py does), each for `n`
+ * photon states of `photons`, which are read and written in place:
+ *   RTMC_PHOP_GENERATE      Photon.GeneratePhoton / ResetPhoton (PhotonObject.py:49-97); the input
+ *                           state is ignored
+ *   RTMC_PHOP_ABSORPTION    Photon.CheckForAbsorption(OldPoint, SmallestDistance)
+ *                           (PhotonObject.py:206-264) with old_point and hit_distance of the batch
+ *                           and Photon.PointCy = args[0..2]; pathway, re-emission and the new free
+ *                           path (MonteCarloFRET.py:63-193, PhotonObject.py:283-305) included
+ *   RTMC_PHOP_REFLECT       Photon.ReflectOnPlane (PhotonObject.py:145-150)
+ *   RTMC_PHOP_REFRACT       Photon.RefractOnPlane(n1, n2) (PhotonObject.py:195-199)
+ *   RTMC_PHOP_LENS          Photon.FocusThinLens(f) (PhotonObject.py:158-186)
+ *   RTMC_PHOP_POLARIZATION  Photon.UpdatePolarization(OldDirection) (PhotonObject.py:117-129)
+ *   RTMC_PHOP_REFLECTANCE   Interface.IsTotalReflect and Interface.Reflectance (Elements.py:75-109):
+ *                           out[2k] = 1 if totally reflected, out[2k+1] = the reflectance
+ *                           (NaN where the reference's is)
+ *   RTMC_PHOP_FREEPATH      Photon.LamBeerDistance (PhotonObject.py:283-305): one exponential
+ *                           variate if the photon's medium absorbs, none otherwise
+ *   RTMC_PHOP_EXECUTE       PrepareExecution + the ExecuteOperation of element number args[6] +
+ *                           PostProcessExecution (PhotonObject.py:135-143; Elements.py:18-24,
+ *                           41-73, 125-129, 152-169) with Photon.PointCy = args[0..2] (cylinders
+ *                           take their tangent plane there, Geometries.py:207-209);
+ *                           out[2k] = 1 if the element counted a bounce, out[2k+1] = 1 if a
+ *                           detector counted the photon for its SpectralCounter
+ * `args` holds RTMC_PHOP_ARGS doubles per photon: [0..2] a point (the support vector of
+ * Photon.OperationPlane, or PointCy), [3..5] the normal of Photon.OperationPlane, [6..8] the
+ * scalars of the call (n1, n2, Photon.sgn | f | element number), [9..11] OldDirection.  `out`
+ * (2 doubles per photon) may be NULL for the operations that return nothing.
+ * Variates come from `tape` as in rtmc_step_tape (tape_pos of the batch is read and advanced;
+ * GENERATE starts at 0).  With `uniform_tape` non-zero every tape value is a uniform in
+ * [0, 1) and the library turns it into the normal or exponential variate an operation asks
+ * for (inverse distribution function), so that a caller who cannot know which kind the next
+ * draw will be can still supply the randomness. */
+#define RTMC_PHOP_GENERATE 1
+#define RTMC_PHOP_ABSORPTION 2
+#define RTMC_PHOP_REFLECT 3
+#define RTMC_PHOP_REFRACT 4
+#define RTMC_PHOP_LENS 5
+#define RTMC_PHOP_POLARIZATION 6
+#define RTMC_PHOP_REFLECTANCE 7
+#define RTMC_PHOP_EXECUTE 8
+#define RTMC_PHOP_FREEPATH 9
+#define RTMC_PHOP_ARGS 12
+int rtmc_op_photon(rtmc_scene *scene, int device, int precision, int op, uint32_t n,
+                   rtmc_photon_soa *photons, const double *args, double *out,
+                   const double *tape, const uint64_t *tape_off, int uniform_tape);
+
 /* Number of wavelengths a photon can carry in this scene (source lines or
  * table rows plus every emission-table row) and their values. */
 int rtmc_scene_wavelengths(const rtmc_scene *scene, int64_t *count, double *values,

@@ -89,6 +89,15 @@ class Cylinder(_Shape):
         self.DirectionVector = np.asarray(DirectionVector, dtype=np.float64)
         self.Photon = Photon
 
+    def OperationPlane(self):
+        """Tangent plane at the photon's candidate point `Photon.PointCy`
+        (Geometries.py:138-153, 207-209): the normal points from that point to
+        its foot on the axis."""
+        point = np.asarray(self.Photon.PointCy, dtype=np.float64)
+        axis = _unit(self.DirectionVector - self.SupportVector)
+        foot = self.SupportVector + np.dot(point - self.SupportVector, axis) * axis
+        return [point, _unit(foot - point)]
+
 
 class Triangle(_Shape):
     kind = "Triangle"

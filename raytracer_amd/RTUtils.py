@@ -2,8 +2,9 @@
 
 Only the photon-independent utilities live here (table lookups, frames, scene
 construction helpers); they run once while a scene is prepared.  Everything
-the reference evaluates per photon (direction samplers, CheckSides,
-RotationMatrix) is device code in csrc/.
+the reference evaluates per photon (direction samplers, RotationMatrix, the
+side test inside the search) is device code in csrc/; `CheckSides` is kept as
+a plain predicate for scripts that call an element's `IsValidNextPoint`.
 """
 from __future__ import annotations
 
@@ -23,6 +24,16 @@ def FindClosestListElement(A, target):
     hi = np.clip(np.searchsorted(A, t, side="left"), 1, len(A) - 1)
     nearer_below = (t - A[hi - 1]) < (A[hi] - t)
     return hi - nearer_below.astype(hi.dtype)
+
+
+def CheckSides(v1, v2, Plane):
+    """True if the points `v1` and `v2` lie on the same side of `Plane` =
+    [support, normal]; a point on the plane is on a side of its own
+    (reference RTUtils.py:6-11 compares the signs of the two plane equations)."""
+    support, normal = (np.asarray(x, dtype=np.float64) for x in Plane)
+    offset = float(np.dot(support, normal))
+    return bool(np.sign(np.dot(normal, np.asarray(v1, dtype=np.float64)) - offset)
+                == np.sign(np.dot(normal, np.asarray(v2, dtype=np.float64)) - offset))
 
 
 def MakeVectAxis(vector):

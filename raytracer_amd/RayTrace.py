@@ -86,6 +86,7 @@ class RayTrace:
         (reference RayTrace.py:70-114; same integer codes and defaults)."""
         self.OpticalElements = []
         self._scene = None
+        self.Photon._attach(self)       # its single-photon operations run on this scene
         for i, shape_code in enumerate(self.ElementGeometry):
             support, direction = self.Elements[i][0], self.Elements[i][1]
             size = self.ElementSize[i]

@@ -27,7 +27,11 @@ STATUS = ["Start", "Absorbed", "ReemittedDonor", "ReemittedAcceptor", "InternalC
 
 EXPORTS = ["rtmc_version", "rtmc_last_error", "rtmc_scene_create", "rtmc_scene_destroy",
            "rtmc_run", "rtmc_last_kernel_ms", "rtmc_step_tape", "rtmc_op_intersect",
-           "rtmc_scene_wavelengths", "rtmc_op_crossing", "rtmc_run_noalloc"]
+           "rtmc_scene_wavelengths", "rtmc_op_crossing", "rtmc_run_noalloc", "rtmc_op_photon"]
+
+PHOP = {"generate": 1, "absorption": 2, "reflect": 3, "refract": 4, "lens": 5, "polarization": 6,
+        "reflectance": 7, "execute": 8, "freepath": 9}          # RTMC_PHOP_*
+PHOP_ARGS = 12
 
 c_double3 = C.c_double * 3
 c_double9 = C.c_double * 9
@@ -132,6 +136,9 @@ def bind(lib):
     lib.rtmc_op_crossing.restype = C.c_int
     lib.rtmc_op_crossing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.POINTER(PhotonSoA),
                                      _i32p, _f64p, _f64p]
+    lib.rtmc_op_photon.restype = C.c_int
+    lib.rtmc_op_photon.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(PhotonSoA),
+                                   _f64p, _f64p, _f64p, _u64p, C.c_int]
     lib.rtmc_scene_wavelengths.restype = C.c_int
     lib.rtmc_scene_wavelengths.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _f64p, C.c_int64]
     return lib

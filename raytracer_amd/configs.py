@@ -278,6 +278,20 @@ def seam_job(n_photons=10, corner=False):
     }
 
 
+def mirror_job(n_photons=7):
+    """One mirror in the plane z = 0 in air and a photon launched from (0, 0, 0.1)
+    straight down: the job the constants of the reference's TestPhoton.py belong to
+    (TestPhoton.py:16,23-25,50-51)."""
+    return {
+        "Elements": np.array([[[0.0, 0.0, 0.0], [0.0, 0.0, 1.0]]]),
+        "ElementProperties": [[1]],
+        "ElementGeometry": [1],
+        "ElementSize": [[5.0, 5.0]],
+        "Materials": [copy.deepcopy(AIR_ROW)],
+        "Photon": [n_photons, [0.0, 0.0, 0.1], STRICT, FIXED_WL, 460, "air", [0.0, 0.0, -1.0], True, 1.0],
+    }
+
+
 def synthetic_am15():
     """Two-column stand-in for the sun table the reference expects in
     `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with

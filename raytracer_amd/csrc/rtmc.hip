@@ -307,6 +307,150 @@ struct SoaDev {
         *tape_pos;
 };
 
+// Tally sink of rtmc_op_photon: what the element counted, for the caller's own counters.
+struct OpTally {
+    int bounced = 0, counted = 0;
+    __device__ __forceinline__ void scalar(int, unsigned long long = 1ull) {}
+    __device__ __forceinline__ void bounce(int) { bounced = 1; }
+    __device__ __forceinline__ void ended(int, bool) {}
+    __device__ __forceinline__ void dump(int, int, int, int, bool was_counted) { counted = was_counted ? 1 : 0; }
+    __device__ __forceinline__ void stamp_begin() {}
+    __device__ __forceinline__ void stamp(int) {}
+};
+
+// One of the single operations of rtmc_op_photon on the photon of this lane.
+// a: the RTMC_PHOP_ARGS arguments of the photon, out: its two result values or null.
+template <typename real>
+__device__ __forceinline__ void photon_operation(const HotScene<real> &sc, const Lds<real> &lds, Photon<real> &p, Rng<real, true> &g,
+                                 int op, const double *a, double hit_distance, double *out)
+{
+    const real nx = real(a[3]), ny = real(a[4]), nz = real(a[5]);
+    // PhotonObject.py:149: (S - L).n / (D.n)
+    const real dn = dot_as_reference(p.Dx, p.Dy, p.Dz, nx, ny, nz);
+    const real off = (p.Lx - real(a[0])) * nx + (p.Ly - real(a[1])) * ny + (p.Lz - real(a[2])) * nz;
+    const real dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+    switch (op) {
+    case RTMC_PHOP_ABSORPTION: {  // PhotonObject.py:206-264
+        const DevMat<real> &m = row(lds.mats, p.mat);
+        if (m.flags & 1) {
+            if (p.dist > real(hit_distance)) {
+                p.dist -= real(hit_distance);
+                p.status = RTMC_ST_START;
+            } else {
+                p.flags = (p.flags | F_ABS_ONCE) & ~F_WAS_EL;
+                p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+                real ux = real(a[0]) - p.Lx, uy = real(a[1]) - p.Ly, uz = real(a[2]) - p.Lz;
+                normalize3(ux, uy, uz);
+                p.Lx += ux * p.dist; p.Ly += uy * p.dist; p.Lz += uz * p.dist;
+                set_admissibility_forward(p);
+                emit_in_reference_order(sc, lds, p, g);
+            }
+        } else {
+            p.status = RTMC_ST_START;
+            p.flags |= F_WAS_EL;
+        }
+        break;
+    }
+    case RTMC_PHOP_REFLECT:
+        move_onto_plane(p, off, dn);
+        reflect_direction(p, dn, nx, ny, nz);
+        break;
+    case RTMC_PHOP_REFRACT: {
+        const real n1 = real(a[6]), n2 = real(a[7]);
+        move_onto_plane(p, off, dn);
+        refract_direction(p, M<real>::has_self_hit_eps ? n1 / n2 : n1 * M<real>::rcp(n2), -dn, real(a[8]), nx, ny, nz);
+        break;
+    }
+    case RTMC_PHOP_LENS: {
+        real cx, cy, cz;
+        move_onto_plane(p, off, dn);
+        focus_thin_lens(p, real(a[6]), off, dn, nz, real(a[2]), cx, cy, cz);
+        break;
+    }
+    case RTMC_PHOP_POLARIZATION: {
+        const real ox = real(a[9]), oy = real(a[10]), oz = real(a[11]);
+        rotate_polarization(p, ox, oy, oz, M<real>::sqrt(ox * ox + oy * oy + oz * oz), false, real(0), real(0), real(0),
+                            real(0));
+        break;
+    }
+    case RTMC_PHOP_REFLECTANCE: {
+        const real n1 = real(a[6]), n2 = real(a[7]);
+        real R;
+        const bool tir = interface_reflectance(p, n1, n2, M<real>::has_self_hit_eps ? n1 / n2 : n1 * M<real>::rcp(n2), dn,
+                                               dnorm, real(a[8]), nx, ny, nz, R);
+        if (out) { out[0] = tir ? 1.0 : 0.0; out[1] = tir ? 1.0 : (double)R; }
+        break;
+    }
+    case RTMC_PHOP_EXECUTE: {
+        const int el = (int)a[6];
+        // line parameter of PointCy
+        const real best_t = ((real(a[0]) - p.Lx) * p.Dx + (real(a[1]) - p.Ly) * p.Dy + (real(a[2]) - p.Lz) * p.Dz) *
+                            M<real>::rcp(dnorm * dnorm);
+        OpTally tally;
+        p.last_el = el;
+        p.best_t = best_t;
+        execute_operation<FEAT_ALL, false>(sc, lds, p, g, tally, row(lds.mats, p.mat), el, false, best_t, dnorm);
+        if (out) { out[0] = tally.bounced; out[1] = tally.counted; }
+        break;
+    }
+    case RTMC_PHOP_FREEPATH: {
+        const DevMat<real> &m = row(lds.mats, p.mat);
+        p.dist = (m.flags & 1) ? free_path<true>(sc, lds, p.mat, m.abs_slot, p, g.expo(0)) : real(0);
+        break;
+    }
+    default: break;
+    }
+}
+
+// The photon of row k of a batch, as the kernels hold it.
+template <typename real>
+__device__ __forceinline__ void soa_load(const SoaDev &b, uint32_t k, const Lds<real> &lds, Photon<real> &p)
+{
+    p.Lx = real(b.loc[0][k]); p.Ly = real(b.loc[1][k]); p.Lz = real(b.loc[2][k]);
+    p.Dx = real(b.dir[0][k]); p.Dy = real(b.dir[1][k]); p.Dz = real(b.dir[2][k]);
+    p.Ex = real(b.efield[0][k]); p.Ey = real(b.efield[1][k]); p.Ez = real(b.efield[2][k]);
+    p.oldx = real(b.old_point[0][k]); p.oldy = real(b.old_point[1][k]); p.oldz = real(b.old_point[2][k]);
+    p.dist = real(b.dist_left[k]);
+    p.psi = real(b.psi[k]);
+    {   // length of the segment that brought the photon here (the float32 guard distance scales with it)
+        const real sx = p.Lx - p.oldx, sy = p.Ly - p.oldy, sz = p.Lz - p.oldz;
+        p.hitd = M<real>::sqrt(sx * sx + sy * sy + sz * sz);
+    }
+    p.wid = b.wid[k]; p.wid0 = b.wid0[k];
+    p.mat = b.material[k]; p.status = b.status[k]; p.last_el = b.last_element[k];
+    p.flags = (b.was_element[k] != 0 ? F_WAS_EL : 0u) | (b.reflected[k] != 0 ? F_REFLECTED : 0u);
+    p.iter = b.iterations[k];
+    p.best_t = real(0);
+    set_admissibility_forward(p);
+    if ((p.flags & F_WAS_EL) && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
+        const DevElem<real> &le = row(lds.elems, p.last_el);
+        real nx = le.nx, ny = le.ny, nz = le.nz;
+        double d0 = (double)le.d0;
+        if ((le.type >> 8) == RTMC_GEOM_CYLINDER) {  // the photon sits on the tangent plane of its last operation
+            cylinder_normal(le, p.Lx, p.Ly, p.Lz, nx, ny, nz);
+            d0 = (double)nx * b.loc[0][k] + (double)ny * b.loc[1][k] + (double)nz * b.loc[2][k];
+        }
+        double s = (double)nx * b.old_point[0][k] + (double)ny * b.old_point[1][k] +
+                   (double)nz * b.old_point[2][k] - d0;
+        set_admissibility(p, le.type & 0xFF, (s > 0) - (s < 0), nx * p.Dx + ny * p.Dy + nz * p.Dz);
+    }
+}
+
+template <typename real>
+__device__ __forceinline__ void soa_store(const SoaDev &b, uint32_t k, const Photon<real> &p, uint32_t tape_pos,
+                                          bool with_hit_distance)
+{
+    b.loc[0][k] = p.Lx; b.loc[1][k] = p.Ly; b.loc[2][k] = p.Lz;
+    b.dir[0][k] = p.Dx; b.dir[1][k] = p.Dy; b.dir[2][k] = p.Dz;
+    b.efield[0][k] = p.Ex; b.efield[1][k] = p.Ey; b.efield[2][k] = p.Ez;
+    b.old_point[0][k] = p.oldx; b.old_point[1][k] = p.oldy; b.old_point[2][k] = p.oldz;
+    b.dist_left[k] = p.dist; b.psi[k] = p.psi;
+    if (with_hit_distance) b.hit_distance[k] = p.hitd;
+    b.wid[k] = p.wid; b.wid0[k] = p.wid0; b.material[k] = p.mat; b.status[k] = p.status;
+    b.last_element[k] = p.last_el; b.was_element[k] = (p.flags & F_WAS_EL) != 0u; b.reflected[k] = (p.flags & F_REFLECTED) != 0u;
+    b.iterations[k] = p.iter; b.tape_pos[k] = (int32_t)tape_pos;
+}
+
 // rtmc_step_tape: one lane per photon, variates from the tape.
 template <typename real>
 __global__ void __launch_bounds__(TRACE_BLOCK)
@@ -325,39 +469,10 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     g.end = (uint32_t)(tape_off[k + 1] - tape_off[k]);
     g.pos = launch ? 0u : (uint32_t)b.tape_pos[k];
     g.overrun = false;
+    g.uniforms_only = false;
     Photon<real> p;
-    if (launch) {
-        launch_in_reference_order(sc, lds, p, g);
-    } else {
-        p.Lx = real(b.loc[0][k]); p.Ly = real(b.loc[1][k]); p.Lz = real(b.loc[2][k]);
-        p.Dx = real(b.dir[0][k]); p.Dy = real(b.dir[1][k]); p.Dz = real(b.dir[2][k]);
-        p.Ex = real(b.efield[0][k]); p.Ey = real(b.efield[1][k]); p.Ez = real(b.efield[2][k]);
-        p.oldx = real(b.old_point[0][k]); p.oldy = real(b.old_point[1][k]); p.oldz = real(b.old_point[2][k]);
-        p.dist = real(b.dist_left[k]);
-        p.psi = real(b.psi[k]);
-        {   // length of the segment that brought the photon here (the float32 guard distance scales with it)
-            const real sx = p.Lx - p.oldx, sy = p.Ly - p.oldy, sz = p.Lz - p.oldz;
-            p.hitd = M<real>::sqrt(sx * sx + sy * sy + sz * sz);
-        }
-        p.wid = b.wid[k]; p.wid0 = b.wid0[k];
-        p.mat = b.material[k]; p.status = b.status[k]; p.last_el = b.last_element[k];
-        p.flags = (b.was_element[k] != 0 ? F_WAS_EL : 0u) | (b.reflected[k] != 0 ? F_REFLECTED : 0u);
-        p.iter = b.iterations[k];
-        p.best_t = real(0);
-        set_admissibility_forward(p);
-        if ((p.flags & F_WAS_EL) && p.last_el >= 0) {  // side of RayTrace.OldPoint w.r.t. the last operation plane
-            const DevElem<real> &le = row(lds.elems, p.last_el);
-            real nx = le.nx, ny = le.ny, nz = le.nz;
-            double d0 = (double)le.d0;
-            if ((le.type >> 8) == RTMC_GEOM_CYLINDER) {  // the photon sits on the tangent plane of its last operation
-                cylinder_normal(le, p.Lx, p.Ly, p.Lz, nx, ny, nz);
-                d0 = (double)nx * b.loc[0][k] + (double)ny * b.loc[1][k] + (double)nz * b.loc[2][k];
-            }
-            double s = (double)nx * b.old_point[0][k] + (double)ny * b.old_point[1][k] +
-                       (double)nz * b.old_point[2][k] - d0;
-            set_admissibility(p, le.type & 0xFF, (s > 0) - (s < 0), nx * p.Dx + ny * p.Dy + nz * p.Dz);
-        }
-    }
+    if (launch) launch_in_reference_order(sc, lds, p, g);
+    else soa_load(b, k, lds, p);
     if (cross_el) {  // rtmc_op_crossing: the search only
         real dnorm;
         const Nearest<real> nr = nearest_valid_hit<FEAT_ALL>(hot, p, dnorm);
@@ -388,14 +503,38 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
         }
     }
     if (g.overrun) *overrun = 1;
-    b.loc[0][k] = p.Lx; b.loc[1][k] = p.Ly; b.loc[2][k] = p.Lz;
-    b.dir[0][k] = p.Dx; b.dir[1][k] = p.Dy; b.dir[2][k] = p.Dz;
-    b.efield[0][k] = p.Ex; b.efield[1][k] = p.Ey; b.efield[2][k] = p.Ez;
-    b.old_point[0][k] = p.oldx; b.old_point[1][k] = p.oldy; b.old_point[2][k] = p.oldz;
-    b.dist_left[k] = p.dist; b.hit_distance[k] = p.hitd; b.psi[k] = p.psi;
-    b.wid[k] = p.wid; b.wid0[k] = p.wid0; b.material[k] = p.mat; b.status[k] = p.status;
-    b.last_element[k] = p.last_el; b.was_element[k] = (p.flags & F_WAS_EL) != 0u; b.reflected[k] = (p.flags & F_REFLECTED) != 0u;
-    b.iterations[k] = p.iter; b.tape_pos[k] = (int32_t)g.pos;
+    soa_store(b, k, p, g.pos, true);
+}
+
+// rtmc_op_photon: one lane per photon, one operation.
+template <typename real>
+__global__ void __launch_bounds__(TRACE_BLOCK)
+photon_op_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, int op, const double *op_args, double *op_out,
+                 const double *tape, const unsigned long long *tape_off, int *overrun, int uniform_tape)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneArg<real> sc = scene_ref(scene);
+    Lds<real> lds = stage_lds(sc, smem, false);
+    const HotScene<real> hot = hot_scene(sc);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const bool launch = op == RTMC_PHOP_GENERATE;
+    Rng<real, true> g;
+    g.tape = tape + tape_off[k];
+    g.end = (uint32_t)(tape_off[k + 1] - tape_off[k]);
+    g.pos = launch ? 0u : (uint32_t)b.tape_pos[k];
+    g.overrun = false;
+    g.uniforms_only = uniform_tape != 0;
+    Photon<real> p;
+    if (launch) {
+        launch_in_reference_order(sc, lds, p, g);
+    } else {
+        soa_load(b, k, lds, p);
+        photon_operation(hot, lds, p, g, op, op_args + (size_t)k * RTMC_PHOP_ARGS, b.hit_distance[k],
+                         op_out ? op_out + 2 * (size_t)k : nullptr);
+    }
+    if (g.overrun) *overrun = 1;
+    soa_store(b, k, p, g.pos, launch);
 }
 
 // rtmc_op_intersect: one lane per (ray, element)
@@ -1322,6 +1461,7 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     const void *trace64 = trace_function<double>(s->features());
     HIP_TRY(hipFuncSetAttribute(trace32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
     HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
+    HIP_TRY(hipFuncSetAttribute((const void *)photon_op_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
     {  // the workgroup size that puts the most waves on a SIMD; the smaller one on a tie
         int best_waves = -1;
         for (int block = TRACE_BLOCK; block <= TRACE_BLOCK_MAX; block += 256) {
@@ -1340,6 +1480,7 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     if (s->img64.lay.total <= 160 * 1024) {
         HIP_TRY(hipFuncSetAttribute(trace64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
         HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
+        HIP_TRY(hipFuncSetAttribute((const void *)photon_op_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace64, TRACE_BLOCK, s->img64.lay.total));
     }
     if (s->hist_in_hbm) {  // one private histogram per workgroup that can be resident, in either precision
@@ -1615,9 +1756,16 @@ struct DeviceBuffer {
 };
 }  // namespace
 
+struct PhotonOp {  // rtmc_op_photon's part of a step_tape_impl call
+    int op = 0;
+    const double *args = nullptr;
+    double *out = nullptr;
+    int uniform_tape = 0;
+};
 static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
                           const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
-                          double *trace, int32_t *cross_el, double *cross_dist, double *cross_pts);
+                          double *trace, int32_t *cross_el, double *cross_dist, double *cross_pts,
+                          const PhotonOp &po = PhotonOp());
 
 RTMC_API int rtmc_step_tape(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
                               const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
@@ -1641,9 +1789,30 @@ RTMC_API int rtmc_op_crossing(rtmc_scene *s, int device, int precision, uint32_t
     });
 }
 
+RTMC_API int rtmc_op_photon(rtmc_scene *s, int device, int precision, int op, uint32_t n, rtmc_photon_soa *b,
+                              const double *args, double *out, const double *tape, const uint64_t *tape_off,
+                              int uniform_tape)
+{
+    if (op < RTMC_PHOP_GENERATE || op > RTMC_PHOP_FREEPATH) return fail(RTMC_EINVAL, "unknown photon operation %d", op);
+    if (op != RTMC_PHOP_GENERATE && !args) return fail(RTMC_EINVAL, "null argument");
+    if (op == RTMC_PHOP_REFLECTANCE && !out) return fail(RTMC_EINVAL, "this operation needs an output array");
+    if (n == 0) return RTMC_OK;
+    return guarded([&] {
+        if (op == RTMC_PHOP_EXECUTE && s)
+            for (uint32_t k = 0; k < n; k++) {
+                const double e = args[(size_t)k * RTMC_PHOP_ARGS + 6];
+                if (!(e >= 0 && e < s->n_el) || e != (double)(int)e) return fail(RTMC_EINVAL, "photon %u: element out of range", k);
+            }
+        PhotonOp po;
+        po.op = op; po.args = args; po.out = out; po.uniform_tape = uniform_tape;
+        return step_tape_impl(s, device, precision, n, b, tape, tape_off, 0, op == RTMC_PHOP_GENERATE, nullptr, nullptr,
+                              nullptr, nullptr, po);
+    });
+}
+
 static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, rtmc_photon_soa *b,
                           const double *tape, const uint64_t *tape_off, uint32_t n_steps, int launch,
-                          double *trace, int32_t *cross_el, double *cross_dist, double *cross_pts)
+                          double *trace, int32_t *cross_el, double *cross_dist, double *cross_pts, const PhotonOp &po)
 {
     const bool crossing = cross_el != nullptr;
     if (!s || !b || !tape || !tape_off) return fail(RTMC_EINVAL, "null argument");
@@ -1692,7 +1861,9 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
     }
     const size_t nd = 15, ni = 9;  // double / int32 columns
     const size_t tape_len = tape_off[n];
-    DeviceBuffer dbuf, ibuf, tbuf, obuf, trbuf, ovbuf, cebuf, cdbuf, cpbuf;
+    DeviceBuffer dbuf, ibuf, tbuf, obuf, trbuf, ovbuf, cebuf, cdbuf, cpbuf, oabuf, oobuf;
+    if (po.args) HIP_TRY(hipMalloc(&oabuf.ptr, 8 * (size_t)RTMC_PHOP_ARGS * n));
+    if (po.out) HIP_TRY(hipMalloc(&oobuf.ptr, 16 * (size_t)n));
     if (crossing) {
         HIP_TRY(hipMalloc(&cebuf.ptr, 4 * (size_t)n));
         HIP_TRY(hipMalloc(&cdbuf.ptr, 8 * (size_t)n));
@@ -1737,9 +1908,22 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
     HIP_TRY(hipMemcpyAsync(tbuf.ptr, tape, 8 * tape_len, hipMemcpyHostToDevice, p.stream));
     HIP_TRY(hipMemcpyAsync(obuf.ptr, tape_off, 8 * (size_t)(n + 1), hipMemcpyHostToDevice, p.stream));
     HIP_TRY(hipMemsetAsync(ovbuf.ptr, 0, 4, p.stream));
+    if (po.args) HIP_TRY(hipMemcpyAsync(oabuf.ptr, po.args, 8 * (size_t)RTMC_PHOP_ARGS * n, hipMemcpyHostToDevice, p.stream));
+    if (po.out) HIP_TRY(hipMemsetAsync(oobuf.ptr, 0, 16 * (size_t)n, p.stream));
     if (trace) HIP_TRY(hipMemcpyAsync(trbuf.ptr, trace, 8 * (size_t)n * n_steps * RTMC_TRACE_STRIDE, hipMemcpyHostToDevice, p.stream));
     const unsigned grid = (n + TRACE_BLOCK - 1) / TRACE_BLOCK;
-    if (f32)
+    if (po.op != 0) {
+        if (f32)
+            hipLaunchKernelGGL(photon_op_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                               (const DevScene<float> *)p.scene32, sd, n, po.op, (const double *)oabuf.ptr,
+                               (double *)oobuf.ptr, (const double *)tbuf.ptr, (const unsigned long long *)obuf.ptr,
+                               (int *)ovbuf.ptr, po.uniform_tape);
+        else
+            hipLaunchKernelGGL(photon_op_kernel<double>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
+                               (const DevScene<double> *)p.scene64, sd, n, po.op, (const double *)oabuf.ptr,
+                               (double *)oobuf.ptr, (const double *)tbuf.ptr, (const unsigned long long *)obuf.ptr,
+                               (int *)ovbuf.ptr, po.uniform_tape);
+    } else if (f32)
         hipLaunchKernelGGL(step_tape_kernel<float>, dim3(grid), dim3(TRACE_BLOCK), lds_bytes, p.stream,
                            (const DevScene<float> *)p.scene32, sd, n, n_steps, launch, (const double *)tbuf.ptr,
                            (const unsigned long long *)obuf.ptr, (double *)trbuf.ptr, (int *)ovbuf.ptr,
@@ -1767,6 +1951,7 @@ static int step_tape_impl(rtmc_scene *s, int device, int precision, uint32_t n, 
     for (size_t j = 0; j < ni; j++) HIP_TRY(hipMemcpyAsync(idst[j], icols[j], 4 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
     if (trace) HIP_TRY(hipMemcpyAsync(trace, trbuf.ptr, 8 * (size_t)n * n_steps * RTMC_TRACE_STRIDE, hipMemcpyDeviceToHost, p.stream));
     int overrun = 0;
+    if (po.out) HIP_TRY(hipMemcpyAsync(po.out, oobuf.ptr, 16 * (size_t)n, hipMemcpyDeviceToHost, p.stream));
     HIP_TRY(hipMemcpyAsync(&overrun, ovbuf.ptr, 4, hipMemcpyDeviceToHost, p.stream));
     HIP_TRY(hipStreamSynchronize(p.stream));
     for (uint32_t k = 0; k < n; k++) {

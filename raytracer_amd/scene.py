@@ -341,6 +341,28 @@ class Scene:
                                              _abi.f64_ptr(pts.reshape(-1))), self.lib)
         return el, dist, pts
 
+    def photon_op(self, op, batch, args=None, tape=None, tape_off=None, uniform_tape=True, device=0,
+                  precision=_abi.F64):
+        """One of the reference's single-photon operations (`_abi.PHOP`) on every
+        photon of `batch`, in place, through rtmc_op_photon.  `args`: (n, 12) array
+        (point, plane normal, three scalars, old direction).  Returns the (n, 2)
+        result array.  Without a tape none of the operation's draws is available."""
+        n = batch["wavelength"].shape[0]
+        a = np.zeros((n, _abi.PHOP_ARGS)) if args is None else np.ascontiguousarray(args, dtype=np.float64)
+        assert a.shape == (n, _abi.PHOP_ARGS)
+        if tape is None:
+            tape, tape_off = np.zeros(1), np.zeros(n + 1, dtype=np.uint64)
+        tape = np.ascontiguousarray(tape, dtype=np.float64)
+        tape_off = np.ascontiguousarray(tape_off, dtype=np.uint64)
+        assert tape_off.shape[0] == n + 1
+        out = np.zeros((n, 2))
+        s = batch_struct(batch)
+        _abi.check(self.lib.rtmc_op_photon(
+            self.handle, int(device), int(precision), int(_abi.PHOP[op]), n, C.byref(s),
+            _abi.f64_ptr(a.reshape(-1)), _abi.f64_ptr(out.reshape(-1)), _abi.f64_ptr(tape),
+            _abi.u64_ptr(tape_off), int(bool(uniform_tape))), self.lib)
+        return out
+
     def wavelengths(self):
         cnt = C.c_int64()
         _abi.check(self.lib.rtmc_scene_wavelengths(self.handle, C.byref(cnt), None, 0), self.lib)

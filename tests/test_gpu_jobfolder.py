@@ -130,14 +130,7 @@ def test_shipped_job_files_on_the_device(tmp_path, golden_dir, oracle_mod):
 def _mirror_scene():
     """One mirror in the plane z = 0 in air: the plane the reference's
     TestPhoton.py reflects on."""
-    job = {
-        "Elements": np.array([[[0.0, 0.0, 0.0], [0.0, 0.0, 1.0]]]),
-        "ElementProperties": [[1]],
-        "ElementGeometry": [1],
-        "ElementSize": [[5.0, 5.0]],
-        "Materials": [configs.copy.deepcopy(configs.AIR_ROW)],
-        "Photon": [7, [0.0, 0.0, 0.1], configs.STRICT, configs.FIXED_WL, 460, "air", [0.0, 0.0, -1.0], True, 1.0],
-    }
+    job = configs.mirror_job()
     rt = RayTrace.RayTrace(demo_scene=False)
     rt.LoadJob(job)
     return rt

@@ -1,0 +1,318 @@
+"""The reference's single-photon methods on the device (`rtmc_op_photon`).
+
+The reference moves one mutable Photon by hand in its TestPhoton.py and in
+the scripts behind its known-answer vectors: PrepareExecution, ReflectOnPlane,
+RefractOnPlane, FocusThinLens, PostProcessExecution, CheckForAbsorption ...
+The host mirror keeps those names; each runs the routine the trace kernel
+itself is built from.  Checked here:
+
+  * the reference's own outputs for 512 interface and 200 thin-lens operations
+    (tests/golden/kat.npz, kat_shapes.npz), through the host methods and as
+    batches in both precisions;
+  * the flow of the reference's TestPhoton.py:35-68, written as there;
+  * search + CheckForAbsorption + ExecuteOperation, called one after the other,
+    reproduce one loop iteration of `rtmc_step_tape` and of the CPU checker on
+    every (photon, iteration) of the golden traces, detector, lens, cylinder,
+    donor/acceptor transfer and aligned dyes included.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import Elements, Materials, PhotonObject, RayTrace, _abi, configs
+from raytracer_amd import scene as sc
+
+pytestmark = pytest.mark.gpu
+
+
+def _standalone(material):
+    return PhotonObject.Photon(EmissionMode="Directional Strict", EmissionDirection=[0, 0, 1.0],
+                               EmissionWavelengthType="fixed", StartingMaterial=material)
+
+
+def test_interface_known_answers_through_the_host_methods(golden_dir):
+    """tests/golden/make_golden.py ran exactly these calls on the reference's objects."""
+    k = np.load(golden_dir + "/kat.npz")
+    air, glass = Materials.MaterialObj("kat_air", 1.0), Materials.MaterialObj("kat_glass", 1.5)
+    photon = _standalone(air)
+    iface = Elements.Interface(air, glass, photon)
+    worst = 0.0
+    for i in range(0, len(k["if_res"]), 4):
+        res, refl = k["if_res"][i], k["if_refl"][i]
+        inside = bool(k["if_inside"][i])
+        n1, n2 = (1.5, 1.0) if inside else (1.0, 1.5)
+
+        def fresh():
+            photon.Location, photon.Direction = k["if_L"][i].copy(), k["if_D"][i].copy()
+            photon.ElectricFieldVector = k["if_E"][i].copy()
+            photon.OperationPlane = [k["if_S"][i].copy(), k["if_n"][i].copy()]
+            photon.CurrentMaterial = glass if inside else air
+            photon.PrepareExecution()
+        fresh()
+        assert photon.sgn == res[2]
+        assert float(iface.IsTotalReflect(n1, n2)) == res[0]
+        if not res[0]:
+            R = iface.Reflectance(n1, n2)
+            assert (np.isnan(R) and np.isnan(res[1])) or R == pytest.approx(res[1], rel=1e-11, abs=1e-14)
+        fresh()
+        photon.RefractOnPlane(n1, n2)
+        photon.PostProcessExecution()
+        got = np.concatenate([photon.Location, photon.Direction, photon.ElectricFieldVector])
+        good = ~np.isnan(res[3:12])
+        assert np.array_equal(np.isnan(got), ~good)
+        worst = max(worst, np.abs(got[good] - res[3:12][good]).max(initial=0.0))
+        fresh()
+        photon.ReflectOnPlane()
+        photon.PostProcessExecution()
+        got = np.concatenate([photon.Location, photon.Direction, photon.ElectricFieldVector])
+        worst = max(worst, np.abs(got - refl).max())
+        assert photon.WasElement
+    assert worst < 1e-11, worst
+
+
+def _plane_batch(L, D, E, s):
+    n = len(L)
+    b = sc.new_photon_batch(n)
+    b["loc"][:], b["dir"][:], b["efield"][:] = L.T, D.T, E.T
+    b["wavelength"][:] = b["start_wavelength"][:] = s.wavelengths()[0]
+    return b
+
+
+@pytest.mark.parametrize("precision,tol", [(_abi.F64, 1e-11), (_abi.F32, 2e-5)])
+def test_interface_and_lens_known_answers_as_batches(golden_dir, precision, tol):
+    k = np.load(golden_dir + "/kat.npz")
+    ks = np.load(golden_dir + "/kat_shapes.npz")
+    photon = _standalone(Materials.MaterialObj("kat_air", 1.0))
+    s = photon._scene()
+    n = len(k["if_res"])
+    args = np.zeros((n, _abi.PHOP_ARGS))
+    args[:, 0:3], args[:, 3:6] = k["if_S"], k["if_n"]
+    args[:, 6] = np.where(k["if_inside"], 1.5, 1.0)
+    args[:, 7] = np.where(k["if_inside"], 1.0, 1.5)
+    args[:, 8] = k["if_res"][:, 2]
+    args[:, 9:12] = k["if_D"]
+    # IsTotalReflect / Reflectance
+    b = _plane_batch(k["if_L"], k["if_D"], k["if_E"], s)
+    out = s.photon_op("reflectance", b, args, precision=precision)
+    near_critical = np.zeros(n, dtype=bool)
+    if precision == _abi.F32:       # within float32 rounding of the critical angle either answer is right
+        c = np.abs(np.einsum("ij,ij->i", k["if_D"], k["if_n"]))
+        near_critical = k["if_inside"] & (np.abs(c * c - (1 - 1 / 2.25)) < 1e-5)
+    assert np.array_equal(out[~near_critical, 0], k["if_res"][~near_critical, 0])
+    part = (k["if_res"][:, 0] == 0) & ~np.isnan(k["if_res"][:, 1]) & ~near_critical
+    assert np.abs(out[part, 1] - k["if_res"][part, 1]).max() < tol
+    if precision == _abi.F64:       # the reference's NaN reflectances are NaN here too
+        assert np.array_equal(np.isnan(out[:, 1]), np.isnan(k["if_res"][:, 1]) & (k["if_res"][:, 0] == 0))
+    # RefractOnPlane + PostProcessExecution
+    b = _plane_batch(k["if_L"], k["if_D"], k["if_E"], s)
+    s.photon_op("refract", b, args, precision=precision)
+    s.photon_op("polarization", b, args, precision=precision)
+    got = np.concatenate([b["loc"].T, b["dir"].T, b["efield"].T], axis=1)
+    ref = k["if_res"][:, 3:12]
+    good = ~np.isnan(ref).any(axis=1)
+    assert np.isnan(got[~good, 3:6]).all()
+    # float32: a refracted ray close to grazing has lost digits in sqrt(1 - sin^2), and a ray that meets
+    # the plane at a shallow angle far away carries the rounding of D.n into its landing point
+    lim = 0.05 if precision == _abi.F32 else 0.0
+    graze = (np.abs(np.einsum("ij,ij->i", ref[:, 3:6], k["if_n"])) < lim) | \
+            (np.abs(np.einsum("ij,ij->i", k["if_D"], k["if_n"])) < lim)
+    scale = np.maximum(1.0, np.abs(ref))
+    assert (np.abs(got - ref) / scale)[good & ~graze].max() < tol
+    # ReflectOnPlane + PostProcessExecution
+    b = _plane_batch(k["if_L"], k["if_D"], k["if_E"], s)
+    s.photon_op("reflect", b, args, precision=precision)
+    s.photon_op("polarization", b, args, precision=precision)
+    got = np.concatenate([b["loc"].T, b["dir"].T, b["efield"].T], axis=1)
+    scale = np.maximum(1.0, np.abs(k["if_refl"]))
+    assert (np.abs(got - k["if_refl"]) / scale)[~graze].max() < tol
+    # FocusThinLens + PostProcessExecution
+    m = len(ks["lens_f"])
+    args = np.zeros((m, _abi.PHOP_ARGS))
+    args[:, 0:3], args[:, 3:6], args[:, 6], args[:, 9:12] = ks["lens_S"], ks["lens_n"], ks["lens_f"], ks["lens_D"]
+    b = _plane_batch(ks["lens_L"], ks["lens_D"], ks["lens_E"], s)
+    s.photon_op("lens", b, args, precision=precision)
+    s.photon_op("polarization", b, args, precision=precision)
+    got = np.concatenate([b["loc"].T, b["dir"].T, b["efield"].T], axis=1)
+    err = np.abs(got - ks["lens_res"])
+    scale = np.maximum(1.0, np.abs(ks["lens_res"]))
+    steep = np.abs(np.einsum("ij,ij->i", ks["lens_D"], ks["lens_n"])) >= lim
+    assert (err / scale)[steep].max() < tol * 10, (err / scale)[steep].max()
+
+
+def test_the_flow_of_the_references_testphoton():
+    """TestPhoton.py:20-68 line by line, on the job its constants belong to: a
+    mirror in the plane z = 0 and a photon launched from (0, 0, 0.1) straight down."""
+    job = configs.mirror_job()
+    RT = RayTrace.RayTrace(demo_scene=False)
+    RT.LoadJob(job)
+    RT.Photon.GeneratePhoton()
+    assert RT.Photon.Location[0] == 0.0 and RT.Photon.Location[1] == 0.0 and RT.Photon.Location[2] == 0.1
+    # test_FindIntersections
+    assert set(RT.OpticalElements[0].Geometry.FindIntersections()) == {0.0}
+    # test_ReflectOnPlane
+    RT.Photon.BeenAbsorbed = [False, 0]
+    RT.OldPoint = RT.Photon.Location
+    RT.Photon.ResetPhoton(RT.Elements[0])
+    RT.CheckElementsForCrossingPoint()
+    RT.Photon.CheckForAbsorption(RT.OldPoint, RT.SmallestDistance)
+    RT.OldPoint = RT.Photon.OldPoint
+    RT.Photon.OperationPlane = RT.OldElement.Geometry.OperationPlane()
+    RT.Photon.ReflectOnPlane()
+    assert set(RT.Photon.Location) == {0.0}
+    assert set(RT.Photon.Direction) == {0.0, -1.0}
+
+    RT.Photon.ResetPhoton(RT.Elements[0])
+    RT.Photon.Direction = np.array([1.0, 1.0, -1.0])
+    RT.CheckElementsForCrossingPoint()
+    RT.Photon.CheckForAbsorption(RT.OldPoint, RT.SmallestDistance)
+    RT.OldPoint = RT.Photon.OldPoint
+    RT.Photon.OperationPlane = RT.OldElement.Geometry.OperationPlane()
+    RT.Photon.ReflectOnPlane()
+    # (the reference asserts these to 0 decimal places against 0.0909...; the point is (0.1, 0.1, 0))
+    assert list(RT.Photon.Location) == pytest.approx([0.1, 0.1, 0.0], abs=1e-15)
+    assert round(float(RT.Photon.Location[0]), 0) == round(0.09090909, 0)
+    # line-based reflection 2 (n.D) n - D (PhotonObject.py:150): the negative of the mirror direction
+    assert list(RT.Photon.Direction) == [-1.0, -1.0, -1.0]
+    # Mirror.ExecuteOperation does the same and counts the bounce
+    RT.Photon.ResetPhoton(RT.Elements[0])
+    RT.Photon.OperationPlane = RT.OpticalElements[0].Geometry.OperationPlane()
+    RT.OpticalElements[0].Type.ExecuteOperation()
+    assert RT.OpticalElements[0].Type.BounceCounter == 1
+    assert list(RT.Photon.Location) == [0.0, 0.0, 0.0] and list(RT.Photon.Direction) == [0.0, 0.0, -1.0]
+    assert RT.OpticalElements[0].Type.IsValidNextPoint(RT.Photon.OldPoint, [0.3, 0.0, 2.0])
+    assert not RT.OpticalElements[0].Type.IsValidNextPoint(RT.Photon.OldPoint, [0.3, 0.0, -2.0])
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            rt = H.raytrace_for(name)
+            cache[name] = (rt, rt.Scene())
+        return cache[name]
+    yield get
+    for rt, s in cache.values():
+        s.close()
+
+
+def _stack(states, g, picks):
+    big = sc.new_photon_batch(len(picks))
+    off = np.zeros(len(picks) + 1, dtype=np.uint64)
+    tapes = []
+    for j, (i, k) in enumerate(picks):
+        for key, arr in states[i].items():
+            if arr.ndim == 2:
+                big[key][:, j] = arr[:, k]
+            else:
+                big[key][j] = arr[k]
+        seg = g["tape"][g["tape_off"][k]:g["tape_off"][k + 1]]
+        tapes.append(seg)
+        off[j + 1] = off[j] + len(seg)
+    return big, np.concatenate(tapes), off
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C6", "C7", "C8", "C9", "C2r"])
+@pytest.mark.parametrize("precision,tol", [(_abi.F64, 1e-10), (_abi.F32, 1e-5)])
+def test_search_absorption_and_execution_make_one_iteration(scenes, oracle_mod, name, precision, tol):
+    """CheckElementsForCrossingPoint, Photon.CheckForAbsorption and the element's
+    ExecuteOperation called one after the other (RayTrace.py:178-189) against one
+    iteration of rtmc_step_tape in the same precision, and in float64 against the CPU
+    checker's next state, with the reference's variates."""
+    from test_gpu_parity import _oracle_states
+    g = H.load_trace(name)
+    rt, s = scenes(name)
+    iters = int(min(25, g["n_iter"].max()))
+    states = _oracle_states(oracle_mod, rt, g, iters)
+    n = len(g["n_iter"])
+    picks = [(i, k) for i in range(iters) for k in range(n)
+             if states[i]["status"][k] not in (4, 5, 6) and states[i]["iterations"][k] == i]
+    whole, tape, off = _stack(states, g, picks)
+    parts = {key: v.copy() for key, v in whole.items()}
+    s.step_tape(whole, tape, off, 1, launch=False, precision=precision)
+    el, dist, pts = s.crossing(parts, precision=precision)
+    found = el >= 0
+    args = np.zeros((len(picks), _abi.PHOP_ARGS))
+    args[:, 0:3] = pts
+    parts["hit_distance"][:] = np.where(found, dist, 0.0)
+    s.photon_op("absorption", parts, args, tape, off, uniform_tape=False, precision=precision)
+    travelling = parts["status"] == 0
+    # the element's operation for the photons that were not absorbed: a batch of its own
+    idx = np.nonzero(found & travelling)[0]
+    sub = {key: (v[:, idx].copy() if v.ndim == 2 else v[idx].copy()) for key, v in parts.items()}
+    sub_off = np.zeros(len(idx) + 1, dtype=np.uint64)
+    sub_tape = []
+    for j, q in enumerate(idx):
+        seg = tape[off[q]:off[q + 1]]
+        sub_tape.append(seg)
+        sub_off[j + 1] = sub_off[j] + len(seg)
+    sub_args = args[idx].copy()
+    sub_args[:, 6] = el[idx]
+    out = s.photon_op("execute", sub, sub_args, np.concatenate(sub_tape), sub_off, uniform_tape=False,
+                      precision=precision)
+    for key, v in sub.items():
+        if v.ndim == 2:
+            parts[key][:, idx] = v
+        else:
+            parts[key][idx] = v
+    assert found.sum() > 0.9 * len(picks) and len(idx) > 0 and (~travelling).sum() >= 0
+    cmp = np.nonzero(found)[0]
+    for key in ("status", "material", "reflected", "was_element", "tape_pos"):
+        assert np.array_equal(parts[key][cmp], whole[key][cmp]), key
+    assert np.array_equal(parts["wavelength"][cmp], whole["wavelength"][cmp])
+    for key in ("loc", "dir", "efield"):
+        assert np.abs(parts[key][:, cmp] - whole[key][:, cmp]).max() < tol, key
+    absorbing = np.array([s.packed.materials[m].IsAbsorber for m in whole["material"]])
+    sel = cmp[absorbing[cmp] & (whole["dist_left"][cmp] < 1e30)]
+    if len(sel):
+        assert (np.abs(parts["dist_left"][sel] - whole["dist_left"][sel])
+                / np.maximum(1.0, np.abs(whole["dist_left"][sel]))).max() < tol
+    # bounces the elements counted = photons that stayed in their medium at a mirror or an interface
+    kinds = np.array([rt.OpticalElements[e].Type.kind for e in el[idx]])
+    reflected = (kinds == "Mirror") | ((kinds == "Interface") & (sub["reflected"] == 1))
+    assert np.array_equal(out[:, 0] == 1, reflected)
+    if precision == _abi.F64:
+        for j in cmp:
+            i, k = picks[j]
+            ref = states[i + 1]
+            assert parts["status"][j] == ref["status"][k] and parts["material"][j] == ref["material"][k]
+            assert parts["wavelength"][j] == ref["wavelength"][k]
+            for key in ("loc", "dir", "efield"):
+                assert np.abs(parts[key][:, j] - ref[key][:, k]).max() < 1e-9, (key, i, k)
+
+
+def test_hand_stepped_photon_reproduces_the_tallies_of_a_run():
+    """A photon moved by hand through the reference's loop body (RayTrace.py:166-199)
+    with the host methods, 200 photons of the Lumogen Red slab: every photon ends, and
+    the fates have the proportions the trace kernel finds (within 5 sigma)."""
+    rt = H.raytrace_for("C2")
+    np.random.seed(7)
+    ph = rt.Photon
+    n, dumped, converted = 200, 0, 0
+    for _ in range(n):
+        ph.ResetPhoton(rt.OpticalElements[0].Geometry.OperationPlane())
+        ph.BeenAbsorbed = [False, 0]
+        ph.Status = "Start"
+        rt.OldPoint = ph.Location
+        rt.OldElement = None
+        if hasattr(rt, "FirstEl"):
+            del rt.FirstEl
+        for i in range(2000):
+            rt.CheckElementsForCrossingPoint()
+            ph.CheckForAbsorption(rt.OldPoint, rt.SmallestDistance)
+            rt.OldPoint = ph.OldPoint
+            if ph.Status == "Start":
+                ph.OperationPlane = rt.OldElement.Geometry.OperationPlane()
+                rt.OldElement.Type.ExecuteOperation()
+                rt.OldPoint = ph.OldPoint
+            if ph.Status in ("InternalConverted", "Dumped"):
+                break
+        assert ph.Status in ("InternalConverted", "Dumped"), ph.Status
+        dumped += ph.Status == "Dumped"
+        converted += ph.Status == "InternalConverted"
+    t = rt.Scene().run(2000000, seed=3)
+    p_ic = t["n_internal_converted"] / 2e6
+    assert abs(converted / n - p_ic) < 5 * np.sqrt(p_ic * (1 - p_ic) / n), (converted, p_ic)
+    counted = sum(oe.Type.Counter for oe in rt.OpticalElements if oe.Type.kind == "Dump")
+    assert counted == dumped == n - converted
