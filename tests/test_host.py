@@ -225,3 +225,32 @@ def test_sun_source_needs_its_table(tmp_path, monkeypatch):
     rt2 = RayTrace.RayTrace(demo_scene=False)
     rt2.LoadJob(job)
     assert np.array_equal(rt2.Photon.sun_table(), configs.synthetic_am15())
+
+
+def test_check_sides_known_answers(golden_dir):
+    """RTUtils.CheckSides against 200 results of the reference's (RTUtils.py:6-11)."""
+    import numpy as np
+    from raytracer_amd import RTUtils
+    k = np.load(golden_dir + "/kat.npz")
+    for i in range(len(k["cs_res"])):
+        assert RTUtils.CheckSides(k["cs_v1"][i], k["cs_v2"][i], k["cs_pl"][i]) == bool(k["cs_res"][i])
+    assert not RTUtils.CheckSides([0, 0, 0.0], [0, 0, 1.0], [[0, 0, 0], [0, 0, 1]])     # a point on the plane
+
+
+def test_cylinder_operation_plane_known_answers(golden_dir):
+    """Cylinder.OperationPlane = [PointCy, normal] with the reference's FindNormalCylinder
+    results (Geometries.py:138-153)."""
+    import numpy as np
+    from raytracer_amd import Geometries, PhotonObject
+    k = np.load(golden_dir + "/kat_shapes.npz")
+    ph = PhotonObject.Photon()
+    seen = 0
+    for i in range(len(k["cyl_R"])):
+        if np.isnan(k["cyl_hit"][i]).any():
+            continue
+        c = Geometries.Cylinder(k["cyl_R"][i], k["cyl_P1"][i], k["cyl_P2"][i], ph)
+        ph.PointCy = k["cyl_hit"][i].copy()
+        point, normal = c.OperationPlane()
+        assert np.allclose(point, k["cyl_hit"][i]) and np.allclose(normal, k["cyl_normal"][i], atol=1e-12)
+        seen += 1
+    assert seen > 50
