@@ -145,6 +145,8 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     tally.lane_steps = 0ull; tally.lane_abs_once = 0u;
 #ifdef RTMC_PROFILE_SECTIONS
     for (int k = 0; k < tally.N_PROF; k++) { tally.prof[k] = 0ull; tally.prof_n[k] = 0u; }
+    // shader clock against the constant 100 MHz counter, over the life of the wave
+    const unsigned long long life_c0 = __builtin_amdgcn_s_memtime(), life_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
     Photon<real> p;
@@ -271,6 +273,8 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     if (lane == 0) {  // per-wave totals behind the work counter
         atomicAdd(&work[8], cyc_renew); atomicAdd(&work[9], n_renew); atomicAdd(&work[10], lanes_renew);
         atomicAdd(&work[11], cyc_step); atomicAdd(&work[12], n_step); atomicAdd(&work[13], lanes_step);
+        atomicAdd(&work[44], __builtin_amdgcn_s_memtime() - life_c0);
+        atomicAdd(&work[45], __builtin_amdgcn_s_memrealtime() - life_r0);
     }
     for (int k = 0; k < tally.N_PROF; k++) {
         atomicAdd(&work[16 + k], tally.prof[k]);
@@ -1629,6 +1633,8 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
                 (double)w[8] / total,
                 ((double)w[8] * (double)w[10] / (double)std::max(1ull, w[9]) +
                  (double)w[11] * (double)w[13] / (double)std::max(1ull, w[12])) / (64.0 * total));
+        fprintf(stderr, "[rtmc]   shader clock while the waves ran: %.0f MHz (cycle counter against the 100 MHz counter, all waves)\n",
+                100.0 * (double)w[44] / (double)std::max(1ull, w[45]));
         static const char *names[9] = {"step: philox", "step: search", "step: absorption check", "step: element operation",
                                        "renew: endings", "renew: pathway + wavelength", "renew: photon ids",
                                        "renew: philox", "renew: direction, polarisation, free path"};
