@@ -443,14 +443,14 @@ def test_reference_demo_scene(oracle_mod):
 
 
 def test_full_size_launch_properties(scenes):
-    """The bench workload at its full size (C2, 2.5e8 photons in one call),
+    """The bench workload at its full size (C2, 1e9 photons in one call),
     checked through what must hold at any size: every photon has exactly one
     fate, per-detector spectra add up to the counters, the energy of a
     red-shifted photon is below one source quantum, the id range can be cut
     anywhere without changing one integer, and the edge efficiency agrees with
     the reference's own runs."""
     rt, s = scenes("C2")
-    n, cut = 250000000, 100000003
+    n, cut = 1000000000, 400000003
     whole = s.run(n, seed=1)
     assert whole["n_photons"] == n
     assert whole["n_dumped"] + whole["n_internal_converted"] + whole["n_capped"] + whole["n_lost"] == n
