@@ -254,3 +254,36 @@ def test_cylinder_operation_plane_known_answers(golden_dir):
         assert np.allclose(point, k["cyl_hit"][i]) and np.allclose(normal, k["cyl_normal"][i], atol=1e-12)
         seen += 1
     assert seen > 50
+
+
+def test_entry_points_refuse_bad_arguments_without_gpu():
+    """Argument checks that come before any device call: every entry point answers a
+    null or nonsensical argument with RTMC_EINVAL and a message, never with a crash."""
+    lib = _abi.load_library()
+    rt = H.raytrace_for("C2")
+    packed = sc.PackedScene(rt.OpticalElements, rt.Photon, rt.MaterialDict)
+    h = ctypes.c_void_p()
+    assert lib.rtmc_scene_create(ctypes.byref(packed.desc), ctypes.byref(h)) == 0
+    try:
+        b = sc.new_photon_batch(2)
+        s = sc.batch_struct(b)
+        args = np.zeros(2 * _abi.PHOP_ARGS)
+        out = np.zeros(4)
+        tape, off = np.zeros(1), np.zeros(3, dtype=np.uint64)
+        call = lambda op, a=args, o=out, n=2: lib.rtmc_op_photon(                       # noqa: E731
+            h, 0, _abi.F64, op, n, ctypes.byref(s), None if a is None else _abi.f64_ptr(a),
+            None if o is None else _abi.f64_ptr(o), _abi.f64_ptr(tape), _abi.u64_ptr(off), 0)
+        assert call(0) == -1 and b"unknown photon operation" in lib.rtmc_last_error()
+        assert call(10) == -1
+        assert call(_abi.PHOP["reflect"], a=None) == -1 and b"null" in lib.rtmc_last_error()
+        assert call(_abi.PHOP["reflectance"], o=None) == -1 and b"output" in lib.rtmc_last_error()
+        args[6] = 99.0                                                                  # no such element
+        assert call(_abi.PHOP["execute"]) == -1 and b"element out of range" in lib.rtmc_last_error()
+        assert call(_abi.PHOP["reflect"], n=0) == 0                                     # nothing to do
+        t, arrays = sc.new_tallies(len(rt.OpticalElements))
+        assert lib.rtmc_run(h, 0, 7, ctypes.c_uint64(1), ctypes.c_uint64(0), ctypes.c_uint64(10), ctypes.byref(t)) == -1
+        assert b"precision" in lib.rtmc_last_error()
+        assert lib.rtmc_run(None, 0, 0, ctypes.c_uint64(1), ctypes.c_uint64(0), ctypes.c_uint64(10), ctypes.byref(t)) == -1
+        assert lib.rtmc_run_noalloc(h, 0, 0, ctypes.c_uint64(1), ctypes.c_uint64(0), ctypes.c_uint64(10), None) == -1
+    finally:
+        lib.rtmc_scene_destroy(h)
