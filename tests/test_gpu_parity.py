@@ -313,6 +313,65 @@ def test_philox_f32_tallies_within_3_sigma_of_reference(scenes, name):
     assert abs(eta_ref - eta_gpu) <= 3 * _sigma(n_ref, eta_gpu) / n_ref * (1 + n_ref / n_gpu) ** 0.5
 
 
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C9", "C2r"])
+def test_spectra_energy_and_bounces_against_reference(scenes, name):
+    """The rest of what the reference's seeded runs hold (tests/golden/ref_tallies.json):
+    the emission spectrum every detector logged (Dump.IncidentSpectrum, Elements.py:159), its
+    EnergyCounter (Elements.py:158) and the BounceCounter of mirrors and interfaces
+    (Elements.py:22,55,71).  Spectra in 20-nm bins: every bin within 4.5 sigma binomial of the
+    reference sample (a hundred bins are tested per configuration) and chi-square over all bins
+    within 3 sigma of its expectation; energy within 3 sigma; bounce totals within 4 standard
+    errors estimated from the scatter of the reference's eight runs."""
+    runs = H.ref_tallies(name)
+    if not runs:
+        pytest.skip("no reference tallies stored for %s" % name)
+    rt, s = scenes(name)
+    n_ref = sum(r["n"] for r in runs)
+    n_gpu = 4000000
+    gpu = s.run(n_gpu, seed=77)
+    width = 20
+    chi2, dof, worst = 0.0, 0, 0.0
+    for i in range(s.n_elements):
+        ref_bins = {}
+        for r in runs:
+            for nm, c in r["hist"].get(str(i), {}).items():
+                ref_bins[int(nm) // width] = ref_bins.get(int(nm) // width, 0) + c
+        row = gpu["spectrum"][i]
+        gpu_bins = {}
+        for b in np.nonzero(row)[0]:
+            key = (200 + int(b)) // width
+            gpu_bins[key] = gpu_bins.get(key, 0) + int(row[b])
+        for key in set(ref_bins) | set(gpu_bins):
+            p = gpu_bins.get(key, 0) / n_gpu
+            expect = p * n_ref
+            got = ref_bins.get(key, 0)
+            if expect < 5:
+                assert got <= 5 + 5 * max(expect, 1.0) ** 0.5, (name, i, key, got, expect)
+                continue
+            var = n_ref * p * (1 - p) * (1 + n_ref / n_gpu)
+            worst = max(worst, abs(got - expect) / var ** 0.5)
+            chi2 += (got - expect) ** 2 / var
+            dof += 1
+    assert dof >= 5 and worst <= 4.5, (name, worst)
+    assert chi2 <= dof + 3 * (2 * dof) ** 0.5, (name, chi2, dof)
+    # EnergyCounter: a sum of per-photon terms in (0, 1], so its variance is at most its mean
+    ref_energy = np.sum([r["energy"] for r in runs], axis=0)
+    for i in range(s.n_elements):
+        expect = float(gpu["energy"][i]) / n_gpu * n_ref
+        assert abs(ref_energy[i] - expect) <= 3 * (expect * (1 + n_ref / n_gpu)) ** 0.5 + 1, (name, i, ref_energy[i], expect)
+    # BounceCounter: heavy-tailed per photon; the reference's own run-to-run scatter is the yardstick
+    per_run = np.array([r["bounce"] for r in runs], dtype=np.float64)
+    same_n = len({r["n"] for r in runs}) == 1
+    for i in range(s.n_elements):
+        expect = float(gpu["bounce"][i]) / n_gpu * n_ref
+        total = per_run[:, i].sum()
+        if expect == 0 and total == 0:
+            continue
+        se = per_run[:, i].std(ddof=1) * len(runs) ** 0.5 if same_n else (expect + 1) ** 0.5 * 10
+        assert abs(total - expect) <= 4 * se + 0.002 * expect + 2, (name, i, total, expect, se)
+    print("%s: %d spectrum bins, worst %.2f sigma, chi-square %.1f for %d" % (name, dof, worst, chi2, dof))
+
+
 @pytest.mark.parametrize("name", ["C2", "C3", "C6", "C7", "C9"])
 def test_production_tallies_against_reference_order_sampling_at_scale(scenes, oracle_mod, name):
     """A sharper version of the 3-sigma test: 2e7 float32 GPU photons against
