@@ -1076,8 +1076,12 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     const rtmc_source &s = d->source;
     DevSource<real> &o = img.src;
     memset(&o, 0, sizeof o);
-    double nrm = std::sqrt(s.direction[0] * s.direction[0] + s.direction[1] * s.direction[1] +
-                           s.direction[2] * s.direction[2]);
+    // PhotonObject.py:86, Direction /= np.linalg.norm(Direction): numpy takes the norm of a 3-vector as
+    // sqrt(dot(x, x)) and sums that dot product as fma(x2, x2, fma(x1, x1, x0 * x0)).  The last bit matters:
+    // a strict source aimed along a tilted plane's normal meets it with a cosine of exactly 1 or 1 + 2^-52
+    // (see interface_reflectance).
+    double nrm = std::sqrt(std::fma(s.direction[2], s.direction[2],
+                                    std::fma(s.direction[1], s.direction[1], s.direction[0] * s.direction[0])));
     for (int j = 0; j < 3; j++) {
         o.loc[j] = (real)s.location[j];
         o.dir[j] = (real)(nrm > 0 ? s.direction[j] / nrm : 0.0);

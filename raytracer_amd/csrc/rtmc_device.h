@@ -1258,6 +1258,15 @@ __device__ __forceinline__ real dot_as_reference(real ax, real ay, real az, real
 }
 
 template <typename real>
+__device__ __forceinline__ void cross_as_reference(real ax, real ay, real az, real bx, real by, real bz, real &cx,
+                                                   real &cy, real &cz)
+{
+    // numpy's cross: every product rounded on its own (no fused multiply-subtract)
+#pragma clang fp contract(off)
+    cx = ay * bz - az * by; cy = az * bx - ax * bz; cz = ax * by - ay * bx;
+}
+
+template <typename real>
 __device__ __forceinline__ void refract_direction(Photon<real> &p, real r, real cc, real sgn, real nx, real ny, real nz)
 {
     if constexpr (M<real>::has_self_hit_eps) {
@@ -1354,8 +1363,16 @@ __device__ __forceinline__ bool interface_reflectance(Photon<real> &p, real n1, 
         // Elements.py:93-94 normalises E here; it already is a unit vector (every rotation and
         // every sampler ends with a normalisation), so only the float64 instantiation repeats it
         if (M<real>::has_self_hit_eps) normalize3(p.Ex, p.Ey, p.Ez);
-        real kx = sgn * (p.Dy * nz - p.Dz * ny), ky = sgn * (p.Dz * nx - p.Dx * nz),
-             kz = sgn * (p.Dx * ny - p.Dy * nx);
+        // D x (sgn n).  float64 rounds the six products on their own, as numpy's cross does: for a
+        // direction that is bit for bit the negative of the normal the result is then exactly zero and
+        // the reference takes its normal-incidence branch (Elements.py:98,107) -- a fused
+        // multiply-subtract would leave the rounding error of one product there instead
+        real kx, ky, kz;
+        if constexpr (M<real>::has_self_hit_eps) {
+            cross_as_reference(p.Dx, p.Dy, p.Dz, sgn * nx, sgn * ny, sgn * nz, kx, ky, kz);
+        } else {
+            kx = sgn * (p.Dy * nz - p.Dz * ny); ky = sgn * (p.Dz * nx - p.Dx * nz); kz = sgn * (p.Dx * ny - p.Dy * nx);
+        }
         real k2 = kx * kx + ky * ky + kz * kz;
         if (!M<real>::has_self_hit_eps) {
             // exactly normal incidence (k = 0): both coefficients equal ((n1 - n2)/(n1 + n2))^2 up to

@@ -139,6 +139,32 @@ def test_interface_and_lens_known_answers_as_batches(golden_dir, precision, tol)
     assert (err / scale)[steep].max() < tol * 10, (err / scale)[steep].max()
 
 
+@pytest.mark.parametrize("precision", [_abi.F64, _abi.F32])
+def test_reflectance_at_exactly_normal_incidence_on_a_tilted_plane(oracle_mod, precision):
+    """A direction that is bit for bit the negative of a tilted plane's normal (a strict source
+    aimed along a rotated slab's normal): numpy sums D.n to 1 + 2^-52 here, the arccos of the
+    reference's Reflectance (Elements.py:87) is NaN -- but its cross product D x n is exactly zero
+    (numpy rounds every product on its own), so it takes the normal-incidence branch
+    ((n1 - n2)/(n1 + n2))^2 (Elements.py:98,107).  The checker and the float64 routine do the same; a
+    fused multiply-subtract in the cross product would leave a rounding residue there and a NaN
+    reflectance (always reflected).  No vector of the reference's own pins this case; it follows from
+    its source as cited."""
+    n = np.array([0.6371277743479907, 0.7070225310439712, 0.3068995597105879])
+    D = -n
+    E = np.cross(D, [0.0, 0.0, 1.0])
+    E /= np.linalg.norm(E)
+    assert abs(float(np.dot(D, n))) > 1.0                    # the case in question
+    r, _, _ = oracle_mod.op_interface(np.zeros(3), n, 1.0, 1.5, np.array([1.0, 1.0, 1.0]), D, E)
+    assert r[0] == 0 and r[1] == pytest.approx(0.04, rel=1e-12)
+    photon = _standalone(Materials.MaterialObj("kat_air", 1.0))
+    s = photon._scene()
+    b = _plane_batch(np.array([[1.0, 1.0, 1.0]]), D[None, :], E[None, :], s)
+    args = np.zeros((1, _abi.PHOP_ARGS))
+    args[0, 3:6], args[0, 6:9] = n, (1.0, 1.5, 1.0)
+    out = s.photon_op("reflectance", b, args, precision=precision)
+    assert out[0, 0] == 0 and out[0, 1] == pytest.approx(0.04, rel=1e-12 if precision == _abi.F64 else 1e-5)
+
+
 def test_the_flow_of_the_references_testphoton():
     """TestPhoton.py:20-68 line by line, on the job its constants belong to: a
     mirror in the plane z = 0 and a photon launched from (0, 0, 0.1) straight down."""
