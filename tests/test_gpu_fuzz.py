@@ -110,3 +110,101 @@ def test_random_scene_float64_follows_the_checker(oracle_mod, seed):
         assert (el32 != el_o).sum() <= m // 400, (el32 != el_o).sum()
     finally:
         s.close()
+
+
+def random_slab_job(seed, n_photons=1000):
+    """The slab with every option of the material and source rows drawn at random: thickness,
+    donor, sun spectrum, aligned acceptors (both forms of the orientation integral), dipole
+    angle, polarisation switch, oblique strict direction, detector efficiency tables, scale
+    factor, fixed donor-acceptor distance."""
+    rng = np.random.RandomState(7000 + seed)
+    aligned = rng.rand() < 0.5
+    d = rng.normal(size=3) * 0.5
+    d[2] = -1.0
+    return configs.slab_job(
+        thickness=float(rng.choice([0.012, 0.05, 0.3, 0.6])), enclosed=True, donor=bool(rng.rand() < 0.6),
+        n_photons=n_photons, sun=bool(rng.rand() < 0.25), aligned=aligned,
+        align_s=float(rng.choice([1e-99, 0.05, 0.3, 0.785, 1.5])) if aligned else 0.1,
+        abs_em_angle=int(rng.choice([0, 10, 45])) if aligned else 0, respect_pol=bool(rng.rand() < 0.7),
+        direction=tuple(float(c) for c in d), eqe=configs.EQE_DEMO if rng.rand() < 0.4 else "",
+        scale=float(rng.choice([0.5, 1.0, 2.0])), fix_dist=bool(rng.rand() < 0.4), fix_dist_r=float(rng.uniform(1.0, 6.0)))
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_slab_options_float64_follows_the_checker(oracle_mod, seed):
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(random_slab_job(seed))
+    s = rt.Scene()
+    try:
+        n = 40000
+        gpu = s.run(n, seed=100 + seed, precision=_abi.F64)
+        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=100 + seed, threads=16)
+        moved = 0
+        for key in ("counter", "bounce", "spectral"):
+            moved += int(np.abs(gpu[key].astype(np.int64) - cpu[key].astype(np.int64)).sum())
+        for key in ("n_absorbed_once", "n_absorptions", "n_internal_converted", "n_dumped", "n_capped", "n_lost",
+                    "n_stale_steps"):
+            moved += abs(int(gpu[key]) - int(cpu[key]))
+        assert gpu["n_photons"] == n and moved <= 12, (seed, moved)
+        assert np.abs(gpu["spectrum"].astype(np.int64) - cpu["spectrum"].astype(np.int64)).sum() <= 12
+        f32 = s.run(n, seed=100 + seed, precision=_abi.F32)
+        moved32 = int(np.abs(f32["counter"].astype(np.int64) - gpu["counter"].astype(np.int64)).sum())
+        assert f32["n_photons"] == n and moved32 <= n // 300, (seed, moved32)
+    finally:
+        s.close()
+
+
+def random_flush_job(seed, n_photons=1000):
+    """The slab in its detector box with one to three extra rectangles lying flush on random
+    faces of the slab (same plane, random footprint, detector or mirror), put at random
+    positions of the element list: equal-distance candidates on every arrival at such a face,
+    and, for float32, elements whose plane passes through the photon's own position."""
+    rng = np.random.RandomState(9000 + seed)
+    job = configs.slab_job(thickness=0.3, enclosed=True, donor=bool(seed % 2), n_photons=n_photons)
+    els = [np.asarray(e, dtype=np.float64) for e in job["Elements"]]
+    props, geo, sizes = list(job["ElementProperties"]), list(job["ElementGeometry"]), list(job["ElementSize"])
+    for _ in range(rng.randint(1, 4)):
+        face = rng.randint(0, 6)
+        support, normal = els[face][0].copy(), els[face][1].copy()
+        size = list(sizes[face][:2])
+        from raytracer_amd.Geometries import Rectangle
+        rect = Rectangle(size[0], size[1], support, normal)
+        shift = rng.uniform(-0.5, 0.5, size=2) * np.array(size)
+        support = support + shift[0] * rect.e1 + shift[1] * rect.e2
+        new_size = [float(size[0] * rng.uniform(0.3, 0.8)), float(size[1] * rng.uniform(0.3, 0.8))]
+        at = rng.randint(0, len(els) + 1)
+        els.insert(at, np.array([support, normal * (1.0 if rng.rand() < 0.5 else -1.0)]))
+        props.insert(at, [4, 0, 0, ""] if rng.rand() < 0.6 else [1])
+        geo.insert(at, 1)
+        sizes.insert(at, new_size)
+    job["Elements"] = np.array(els)
+    job["ElementProperties"], job["ElementGeometry"], job["ElementSize"] = props, geo, sizes
+    d = rng.normal(size=3) * 0.3
+    d[2] = -1.0
+    job["Photon"][6] = [float(c) for c in d]
+    return job
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_flush_elements_follow_the_checker(oracle_mod, seed):
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(random_flush_job(seed))
+    s = rt.Scene()
+    try:
+        n = 40000
+        gpu = s.run(n, seed=300 + seed, precision=_abi.F64)
+        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=300 + seed, threads=16)
+        moved = 0
+        for key in ("counter", "bounce", "spectral"):
+            moved += int(np.abs(gpu[key].astype(np.int64) - cpu[key].astype(np.int64)).sum())
+        for key in ("n_absorbed_once", "n_absorptions", "n_internal_converted", "n_dumped", "n_capped", "n_lost",
+                    "n_stale_steps"):
+            moved += abs(int(gpu[key]) - int(cpu[key]))
+        assert gpu["n_photons"] == n and moved <= 12, (seed, moved)
+        # float32: the guard distance stands in for the reference's 1e-8 cm; photons within a few
+        # float32 steps of a seam may take the other element
+        f32 = s.run(n, seed=300 + seed, precision=_abi.F32)
+        moved32 = int(np.abs(f32["counter"].astype(np.int64) - gpu["counter"].astype(np.int64)).sum())
+        assert f32["n_photons"] == n and moved32 <= n // 200, (seed, moved32)
+    finally:
+        s.close()
