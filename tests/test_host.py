@@ -287,3 +287,30 @@ def test_entry_points_refuse_bad_arguments_without_gpu():
         assert lib.rtmc_run_noalloc(h, 0, 0, ctypes.c_uint64(1), ctypes.c_uint64(0), ctypes.c_uint64(10), None) == -1
     finally:
         lib.rtmc_scene_destroy(h)
+
+
+def test_random_jobs_survive_the_prt_round_trip(tmp_path):
+    """Job folders of the random scenes the GPU tests use (every shape and element type,
+    explicit in-plane axes, triangles given by their corners, option rows drawn at random):
+    written as the six .prt files and read back, nothing changes, and the host objects built
+    from the copy are the ones built from the original."""
+    from test_gpu_fuzz import random_flush_job, random_job, random_slab_job
+
+    def plain(x):
+        if isinstance(x, np.ndarray):
+            return plain(x.tolist())
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        if isinstance(x, (np.floating, np.integer, np.bool_)):
+            return x.item()
+        return x
+    for k, make in enumerate([random_job] * 8 + [random_slab_job] * 6 + [random_flush_job] * 4):
+        job = make(k)
+        job.pop("SunTable", None)
+        folder = tmp_path / ("job%d" % k)
+        folder.mkdir()
+        prt.dump_job(str(folder), job)
+        back = prt.load_job(str(folder))
+        assert np.allclose(np.array(back["Elements"], dtype=np.float64), np.array(job["Elements"], dtype=np.float64), rtol=0, atol=0)
+        for key in ("ElementProperties", "ElementGeometry", "ElementSize", "Materials", "Photon"):
+            assert plain(back[key]) == plain(job[key]), (k, key)
