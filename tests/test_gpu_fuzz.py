@@ -208,3 +208,27 @@ def test_random_flush_elements_follow_the_checker(oracle_mod, seed):
         assert f32["n_photons"] == n and moved32 <= n // 200, (seed, moved32)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("cap", [1, 2, 3, 7, 40])
+def test_small_iteration_caps_follow_the_checker(oracle_mod, cap):
+    """The loop's cap (`i >= 1e4` tested after the step in the reference, RayTrace.py:193; here a
+    parameter) at values where most photons meet it: fates, the iteration count and every tally as
+    the checker has them, in float64 photon for photon and in float32."""
+    for name in ("C3", "C4"):
+        rt = RayTrace.RayTrace(demo_scene=False)
+        rt.LoadJob(configs.make_job(name, 1000))
+        rt.MaxIterations = cap
+        s = rt.Scene()
+        try:
+            n = 30000
+            cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=9, threads=16)
+            assert (cap > 10 or cpu["n_capped"] > 0) and cpu["n_steps"] <= cap * n
+            for precision, slack in ((_abi.F64, 4), (_abi.F32, n // 300)):
+                gpu = s.run(n, seed=9, precision=precision)
+                moved = int(np.abs(gpu["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum())
+                for key in ("n_steps", "n_capped", "n_dumped", "n_internal_converted", "n_absorbed_once"):
+                    moved += abs(int(gpu[key]) - int(cpu[key]))
+                assert gpu["n_photons"] == n and moved <= slack, (name, cap, precision, moved)
+        finally:
+            s.close()
