@@ -232,3 +232,35 @@ def test_small_iteration_caps_follow_the_checker(oracle_mod, cap):
                 assert gpu["n_photons"] == n and moved <= slack, (name, cap, precision, moved)
         finally:
             s.close()
+
+
+def test_photon_ids_beyond_32_bits(oracle_mod):
+    """Photon ids are 64-bit (the Philox counter carries both halves): ranges that straddle 2^32
+    and ranges far beyond it follow the checker photon for photon, and a range cut at 2^32 adds up
+    to the whole, bit for bit."""
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.make_job("C3", 1000))
+    s = rt.Scene()
+    o = oracle_mod.OracleScene.from_raytrace(rt)
+    try:
+        n = 40000
+        for first in (2 ** 32 - n // 2, 2 ** 32, 2 ** 40 + 12345, 2 ** 63 - n):
+            gpu = s.run(n, seed=21, first_photon=first, precision=_abi.F64)
+            cpu = o.run_threads(n, seed=21, first_photon=first, threads=16)
+            moved = int(np.abs(gpu["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum())
+            moved += abs(int(gpu["n_steps"]) - int(cpu["n_steps"])) + abs(int(gpu["n_internal_converted"]) - int(cpu["n_internal_converted"]))
+            assert gpu["n_photons"] == n and moved <= 4, (first, moved)
+        first = 2 ** 32 - n // 2
+        whole = s.run(n, seed=21, first_photon=first)
+        block = sc.new_tallies(s.n_elements)
+        s.run(n // 2, seed=21, first_photon=first, tallies=block)
+        s.run(n - n // 2, seed=21, first_photon=2 ** 32, tallies=block)
+        parts = sc.tallies_to_dict(*block)
+        for key in ("counter", "spectral", "bounce", "energy_fx", "spectrum"):
+            assert np.array_equal(whole[key], parts[key]), key
+        # ids below and above 2^32 are different photons
+        low = s.run(n, seed=21, first_photon=0)
+        high = s.run(n, seed=21, first_photon=2 ** 32)
+        assert not np.array_equal(low["counter"], high["counter"])
+    finally:
+        s.close()
