@@ -108,11 +108,11 @@ enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3, NEED_RETIRE 
 #endif
 constexpr int RENEW_DEBT = RTMC_RENEW_DEBT;  // lane-iterations
 
-// Register budget: the float32 kernels are held to 80 VGPRs so that six waves
-// share a SIMD (three 512-thread workgroups per CU); the loop waits on LDS
-// gathers and scalar loads often enough that 6 waves run 13 % faster than the
-// 4 that the unconstrained allocation (90 VGPRs) allows, at the price of one
-// 8-byte spill.  float64 (validation only) is left unconstrained.
+// Register budget: the float32 kernels are compiled for six waves per SIMD
+// (three 512-thread workgroups per CU, at most 80 VGPRs; the lean instantiation
+// takes 62).  Six waves run 13 % faster than four; seven or eight (which 62
+// registers would allow) run slower.  float64 (validation only) is left
+// unconstrained.
 #ifndef RTMC_TRACE_WAVES
 #define RTMC_TRACE_WAVES 6
 #endif
