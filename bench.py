@@ -55,11 +55,11 @@ def kernel_source_digest():
     return h.hexdigest()
 
 
-def measured_traffic(config, per_step):
-    """HBM bytes per launch from the committed counter passes (profiles/) --
-    only if they were taken on this workload, this launch size and exactly
-    these kernel sources; None (JSON null) otherwise, so that a figure from an
-    older kernel is never reported for a newer one."""
+def committed_counters(config, per_step):
+    """The committed counter passes (profiles/*_traffic.json) -- only if they were
+    taken on this workload, this launch size and exactly these kernel sources;
+    None otherwise, so that a figure from an older kernel is never reported for
+    a newer one."""
     best = None
     pdir = os.path.join(REPO, "profiles")
     digest = kernel_source_digest()
@@ -70,8 +70,48 @@ def measured_traffic(config, per_step):
                     t = json.load(fh)
                 if (t.get("workload") == config and int(t.get("photons_per_launch", 0)) == per_step
                         and t.get("kernel_source_sha256") == digest):
-                    best = float(t["hbm_bytes_per_launch"])
+                    best = t
     return best
+
+
+def measured_traffic(config, per_step):
+    """HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes, or None (JSON null)."""
+    t = committed_counters(config, per_step)
+    return None if t is None else float(t["hbm_bytes_per_launch"])
+
+
+N_SIMD = 256 * 4           # SIMDs of one MI355X
+# SIMD cycles one wave-instruction occupies the vector pipe, measured per instruction class at the
+# kernel's own occupancy (tools/ubench/valu_rates.hip, profiles/r02_valu_rates.txt)
+CYCLES_PLAIN, CYCLES_TRANS = 2.4, 8.2
+
+
+def executed_work(config, per_step, kernel_s, clock_hz=2.37e9):
+    """What the kernel executed per launch, from the committed counter passes (same digest rule as
+    the traffic): VALU lane occupancy, the share of the SIMDs' vector-issue cycles it used, and the
+    float32 operations its FMA / MUL / ADD instructions performed on active lanes.  None if the
+    counters do not belong to the present sources."""
+    t = committed_counters(config, per_step)
+    if t is None or "SQ_INSTS_VALU" not in t:
+        return None
+    valu, lanes = float(t["SQ_INSTS_VALU"]), float(t["SQ_THREAD_CYCLES_VALU"])
+    trans = float(t.get("SQ_INSTS_VALU_TRANS_F32", 0.0))
+    occupancy = lanes / (64.0 * valu)
+    # a lower bound: instructions with a scalar operand, v_cmpx and the 32x32->64 multiplies of Philox
+    # cost more than the plain rate (4.2 / 4.8 / 5.4 cycles in a stream of their own)
+    issue_cycles = (valu - trans) * CYCLES_PLAIN + trans * CYCLES_TRANS
+    wave_flops = 2.0 * float(t["SQ_INSTS_VALU_FMA_F32"]) + float(t["SQ_INSTS_VALU_MUL_F32"]) + float(t["SQ_INSTS_VALU_ADD_F32"])
+    return {
+        "lane_occupancy": occupancy,
+        "valu_issue_frac": issue_cycles / (N_SIMD * clock_hz * kernel_s),
+        "executed_fp32_tflops": wave_flops * 64.0 * occupancy / kernel_s / 1e12,
+        "executed_fp32_tflops_all_lanes": wave_flops * 64.0 / kernel_s / 1e12,
+        "valu_wave_instructions_per_photon": valu / per_step,
+        "note": "SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F32 of one launch "
+                "(rocprofv3 --pmc passes, profiles/), priced with the measured issue cost per instruction class "
+                "(%.1f SIMD cycles, %.1f for transcendentals: a lower bound) at %.2f GHz; duration = this run's kernel time"
+                % (CYCLES_PLAIN, CYCLES_TRANS, clock_hz * 1e-9),
+    }
 
 
 def launch_ranks(args, argv):
@@ -107,7 +147,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--photons-per-step", type=float, default=1e9)
+    ap.add_argument("--photons-per-step", type=float, default=1e9,
+                    help="weak scaling (default): photons per step on every GPU")
+    ap.add_argument("--total-photons", type=float, default=None,
+                    help="strong scaling: photons per step over all ranks together; every rank takes "
+                         "its shard_range of them")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -144,7 +188,13 @@ def main():
     from raytracer_amd import RayTrace, configs, _abi, distributed
     from raytracer_amd import scene as sc
 
-    per_step = int(args.photons_per_step)
+    strong = args.total_photons is not None
+    if strong:      # one step = `total` photon ids, cut into contiguous blocks, one per rank
+        total = int(args.total_photons)
+        shard_first, per_step = distributed.shard_range(total, rank, world)
+    else:           # one step = per_step ids on every rank
+        per_step = int(args.photons_per_step)
+        total, shard_first = per_step * world, rank * per_step
     rt = RayTrace.RayTrace(demo_scene=False)
     rt.LoadJob(configs.make_job(args.config, per_step))
     scene = rt.Scene()
@@ -157,7 +207,7 @@ def main():
 
     # every (rank, step) gets its own photon-id range
     def first_id(step_index):
-        return (step_index * world + rank) * per_step
+        return step_index * total + shard_first
 
     block = sc.new_tallies(n_el)
     # set-up, not a step: device context, scene tables into HBM, kernel code object
@@ -185,17 +235,17 @@ def main():
 
     out = None
     if rank == 0 and args.dump_tallies:
-        np.savez(args.dump_tallies, first_photon=first_id(args.warmup) - rank * per_step,
-                 n_requested=per_step * args.steps * world,
+        np.savez(args.dump_tallies, first_photon=first_id(args.warmup) - shard_first,
+                 n_requested=total * args.steps,
                  **{k: tall[k] for k in list(_abi.TALLY_SCALARS) + list(_abi.TALLY_ARRAYS) + ["spectrum"]})
     if rank == 0:
-        total_photons = per_step * args.steps * world
+        total_photons = total * args.steps
         assert tall["n_photons"] == total_photons, (tall["n_photons"], total_photons)
         iters_per_launch = tall["n_steps"] / (args.steps * world)
         avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
         flops = iters_per_launch * flops_per_iteration(n_el)
         achieved = flops / avg_kernel_s / 1e12
-        alg_bytes = per_step * 96.0     # one register-resident photon record per photon
+        traffic = measured_traffic(args.config, per_step)
         edges = [2, 3, 4, 5]
         out = {
             "metric": "photons/sec",
@@ -206,14 +256,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s: Lumogen Red slab 5x5x0.3 cm in a detector box, 460 nm "
                                    "source, %d rectangles" % (args.config, n_el)
                        if args.config == "C2" else args.config,
-                       "photons_per_step_per_gpu": per_step,
+                       "photons_per_step_per_gpu": per_step if not strong else None,
+                       "photons_per_step_total": total,
                        "parallelism": "photon-id ranges, %d rank(s)" % world,
                        "iterations_per_photon": tall["n_steps"] / tall["n_photons"],
                        "optical_efficiency": float(tall["counter"][edges].sum()) / tall["n_photons"],
@@ -221,13 +272,18 @@ def main():
                        "capped": int(tall["n_capped"]), "lost": int(tall["n_lost"])},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                         "traffic": measured_traffic(args.config, per_step),
+                         "traffic": traffic,
                          "kernel": "trace_kernel<float, 0>", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "flop_per_iteration": flops_per_iteration(n_el),
                          "iterations_per_launch": iters_per_launch,
-                         "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "frac": alg_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS,
-                                 "algorithmic_bytes_per_photon": 96}},
+                         "executed": executed_work(args.config, per_step, avg_kernel_s),
+                         # the photons never leave the registers: what crosses HBM is the measured
+                         # traffic (scene tables in, per-workgroup tallies out), not 96 B per photon
+                         "hbm": {"achieved": None if traffic is None else traffic / avg_kernel_s / 1e9,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": None if traffic is None else traffic / avg_kernel_s / 1e9 / PEAK_HBM_GBS,
+                                 "photon_record_bytes_kept_in_registers": 96}},
+            "collective": distributed.collective_info(block),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, int(args.cpu_sample), args.seed, args.config)

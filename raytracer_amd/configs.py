@@ -252,7 +252,7 @@ def flush_detector_job(n_photons=10000):
     return job
 
 
-def seam_job(n_photons=10, corner=False):
+def seam_job(n_photons=10, corner=False, start=(0.0, 2.0, 0.75), direction=(0.0, 0.5, -0.5)):
     """Strict sources aimed exactly at a seam, with coordinates that are exact in
     float32 and float64, so that the candidates tie bit for bit.
     corner=False: a 0.25 cm slab, source at (0, 2, 0.75) along (0, 0.5, -0.5): the
@@ -263,8 +263,8 @@ def seam_job(n_photons=10, corner=False):
     (1, 1, 0.5): the faces z = 2, x = 4 and y = 4 (elements 0, 2, 4) meet at
     parameter 4."""
     if not corner:
-        job = slab_job(thickness=0.25, enclosed=True, n_photons=n_photons, direction=(0.0, 0.5, -0.5))
-        job["Photon"][1] = [0.0, 2.0, 0.75]
+        job = slab_job(thickness=0.25, enclosed=True, n_photons=n_photons, direction=tuple(direction))
+        job["Photon"][1] = [float(c) for c in start]
         return job
     e, p, sz = _dump_box(0.0, 0.0, 0.0, 4.0, 2.0)
     order = [4, 5, 0, 1, 2, 3]
@@ -289,6 +289,41 @@ def mirror_job(n_photons=7):
         "ElementSize": [[5.0, 5.0]],
         "Materials": [copy.deepcopy(AIR_ROW)],
         "Photon": [n_photons, [0.0, 0.0, 0.1], STRICT, FIXED_WL, 460, "air", [0.0, 0.0, -1.0], True, 1.0],
+    }
+
+
+ESCAPE_CONE_COS = float(np.sqrt(1.0 - (1.0 / 1.5) ** 2))    # cos of the critical angle 41.81 deg of n = 1.5
+
+
+def escape_cone_job(n_photons=10000, emission=False):
+    """The geometry of the reference's manual check TESTEMISSION (MonteCarloFRET.py:283-308): which
+    fraction of isotropic directions lies outside the escape cone of a medium with n = 1.5 (41.81
+    degrees about the z axis; expected cos(41.81 deg) = 0.7454)?  A point source at (0, 0, 1); two
+    round detectors (elements 0 and 1) in the planes z = 0 and z = 2 cover exactly that cone, up
+    and down; a closed detector box catches the rest.
+    emission=False: a hemispherical source in air (the launch sampler, PhotonObject.py:68-86).
+    emission=True: the source sits *inside* a dye medium with n = 1.5 and a vanishing
+    concentration: every photon is absorbed on the spot (the free path of a new photon is zero,
+    PhotonObject.py:32) and re-emitted isotropically from the source point (MonteCarloFRET.py:92-105,
+    170-175) -- or lost to internal conversion --, then flies to a detector unhindered."""
+    r = float(np.sqrt(1.0 - ESCAPE_CONE_COS ** 2) / ESCAPE_CONE_COS)   # tan of the critical angle
+    els = [[[0.0, 0.0, 0.0], [0.0, 0.0, 1.0]], [[0.0, 0.0, 2.0], [0.0, 0.0, 1.0]]]
+    props = [[4, 0, 0, ""], [4, 0, 0, ""]]
+    geom, sizes = [2, 2], [[r], [r]]
+    e, p, sz = _dump_box(0.0, 0.0, 1.0, 4.0, 1.5)
+    els, props, geom, sizes = els + e, props + p, geom + [1] * 6, sizes + sz
+    mats = [copy.deepcopy(AIR_ROW)]
+    if emission:
+        mats.append(dye_row("LRthin", conc_a=1e-9))
+    photon = _photon(n_photons, (0.0, 0.0, 1.0), STRICT if emission else ISOTROPIC, FIXED_WL, 460,
+                     "LRthin" if emission else "air", (0.0, 0.0, -1.0))
+    return {
+        "Elements": np.array(els, dtype=np.float64),
+        "ElementProperties": props,
+        "ElementGeometry": geom,
+        "ElementSize": sizes,
+        "Materials": mats,
+        "Photon": photon,
     }
 
 

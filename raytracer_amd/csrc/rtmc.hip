@@ -437,6 +437,10 @@ __device__ __forceinline__ void soa_load(const SoaDev &b, uint32_t k, const Lds<
         double s = (double)nx * b.old_point[0][k] + (double)ny * b.old_point[1][k] +
                    (double)nz * b.old_point[2][k] - d0;
         set_admissibility(p, le.type & 0xFF, (s > 0) - (s < 0), nx * p.Dx + ny * p.Dy + nz * p.Dz);
+        // uncertainty of the landing point: the segment old point -> here met the plane under |s| / segment
+        const real reach = real(s > 0 ? s : -s);
+        const bool oblique = (p.hitd > real(0)) & (reach > real(0));
+        p.guard = landing_uncertainty(p, p.hitd, oblique ? p.hitd : real(1), oblique ? reach : real(1));
     }
 }
 
@@ -765,10 +769,11 @@ struct rtmc_scene {
     bool has_back = false;          // some medium's acceptor can hand the excitation back to its donor
     bool has_frames = false;        // some rectangle is tested in a frame other than the world's
     bool has_coplanar = false;      // two elements overlap in one plane: the float32 kernels keep a guard distance
+    bool seam_source = false;       // a strict source is aimed at a seam: guard distance until a photon's first absorption
     bool hist_in_hbm = false;       // detectors x bins too large for the LDS in some precision
     int features() const
     {
-        if (has_area || has_coplanar || hist_in_hbm) return FEAT_ALL;
+        if (has_area || has_coplanar || seam_source || hist_in_hbm) return FEAT_ALL;
         return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES | FEAT_FRAMES : 0) |
                (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0);
     }
@@ -1144,6 +1149,61 @@ bool coplanar_overlap(const rtmc_scene_desc *d)
     return false;
 }
 
+// Is a strict source aimed at a seam: does its line first land (float64) on a point that belongs to
+// a second flat element as well, within what float32 cannot resolve?  Every photon of such a source
+// then sits on both elements after its first operation.  Only the first landing point is examined;
+// cylinder walls are left out (as first element and as neighbour).
+bool strict_source_meets_seam(const rtmc_scene_desc *d)
+{
+    const rtmc_source &s = d->source;
+    if (s.direction_mode != 0 || s.area[0] != 0.0 || s.area[1] != 0.0) return false;
+    auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    const double dn = std::sqrt(dot(s.direction, s.direction));
+    if (!(dn > 0)) return false;
+    const double D[3] = {s.direction[0] / dn, s.direction[1] / dn, s.direction[2] / dn};
+    // is point P a point of flat element e, its outline widened by tol?
+    auto contains = [&](const rtmc_element &e, const double *P, double tol) {
+        const double v[3] = {P[0] - e.support[0], P[1] - e.support[1], P[2] - e.support[2]};
+        if (std::fabs(dot(v, e.normal)) > tol) return false;
+        if (e.geometry == RTMC_GEOM_RECTANGLE)
+            return std::fabs(dot(v, e.e1)) <= e.half1 + tol && std::fabs(dot(v, e.e2)) <= e.half2 + tol;
+        if (e.geometry == RTMC_GEOM_CIRCLE) return std::sqrt(dot(v, v)) <= e.half1 + tol;
+        // triangle (corners in e1, e2, vertex3): on the inner side of every edge, each moved out by tol
+        const double *c[3] = {e.e1, e.e2, e.vertex3};
+        int pos = 0, neg = 0;
+        for (int k = 0; k < 3; k++) {
+            const double *a = c[k], *b = c[(k + 1) % 3];
+            const double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ap[3] = {P[0] - a[0], P[1] - a[1], P[2] - a[2]};
+            const double cr[3] = {ab[1] * ap[2] - ab[2] * ap[1], ab[2] * ap[0] - ab[0] * ap[2], ab[0] * ap[1] - ab[1] * ap[0]};
+            const double side = dot(cr, e.normal) / std::max(1e-300, std::sqrt(dot(ab, ab)));  // signed distance from the edge
+            if (side > tol) pos++;
+            if (side < -tol) neg++;
+        }
+        return pos == 0 || neg == 0;
+    };
+    double reach = std::sqrt(dot(s.location, s.location));
+    for (int i = 0; i < d->n_elements; i++) reach = std::max(reach, std::sqrt(dot(d->elements[i].support, d->elements[i].support)));
+    const double tol = 64.0 / 16777216.0 * (1.0 + reach);   // a few times the float32 guard distance
+    double t0 = 1e300;
+    int first = -1;
+    for (int i = 0; i < d->n_elements; i++) {
+        const rtmc_element &e = d->elements[i];
+        if (e.geometry == RTMC_GEOM_CYLINDER) continue;
+        const double den = dot(D, e.normal);
+        if (std::fabs(den) < 1e-12) continue;
+        const double w[3] = {e.support[0] - s.location[0], e.support[1] - s.location[1], e.support[2] - s.location[2]};
+        const double t = dot(w, e.normal) / den;
+        if (!(t > tol) || t >= t0) continue;
+        const double P[3] = {s.location[0] + t * D[0], s.location[1] + t * D[1], s.location[2] + t * D[2]};
+        if (contains(e, P, tol)) { t0 = t; first = i; }
+    }
+    if (first < 0) return false;
+    const double P[3] = {s.location[0] + t0 * D[0], s.location[1] + t0 * D[1], s.location[2] + t0 * D[2]};
+    for (int i = 0; i < d->n_elements; i++)
+        if (i != first && d->elements[i].geometry != RTMC_GEOM_CYLINDER && contains(d->elements[i], P, tol)) return true;
+    return false;
+}
+
 int get_table(const rtmc_scene_desc *d, rtmc_table ref, HostTable &t, const char *what)
 {
     if (ref.len < 2 || ref.offset < 0 || ref.offset + 2 * ref.len > d->table_data_len)
@@ -1279,6 +1339,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
         if (d->elements[i].type == RTMC_TYPE_DUMP && d->elements[i].eqe_table >= 0) s->has_spectra = true;
     s->elements.assign(d->elements, d->elements + d->n_elements);
     s->has_coplanar = coplanar_overlap(d);
+    s->seam_source = strict_source_meets_seam(d);
     s->wl = wl;
     s->el_eqe.resize(s->n_el);
     for (int i = 0; i < s->n_el; i++) s->el_eqe[i] = d->elements[i].type == RTMC_TYPE_DUMP ? d->elements[i].eqe_table : -1;
@@ -1529,7 +1590,7 @@ static DevScene<real> device_scene(const rtmc_scene *s, const PerDevice &p, cons
     sc.src = img.src;
     sc.lay = img.lay;
     sc.n_el = s->n_el; sc.n_mat = s->n_mat; sc.max_iter = s->max_iter;
-    sc.use_guard = s->has_coplanar ? 1 : 0;
+    sc.use_guard = s->has_coplanar ? 1 : (s->seam_source ? 2 : 0);
     return sc;
 }
 

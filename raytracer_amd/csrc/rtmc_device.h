@@ -195,7 +195,9 @@ struct HotScene {
     int32_t n_group[4];
     int32_t n_wid, max_iter;
     real inv_scale;
-    int32_t use_guard;  // float32 kernels with FEAT_GUARD: the scene has coplanar overlapping elements
+    int32_t use_guard;  // float32 kernels with FEAT_GUARD: 0 no guard distance, 1 on every search (the scene has
+                        // coplanar overlapping elements), 2 until a photon's first absorption (a strict source
+                        // is aimed at a seam: up to there the landing points are the same for every photon)
 };
 
 // Code a scene may need beyond rectangles with isotropic dyes; kernels are
@@ -394,6 +396,9 @@ struct Photon {
     // Admissibility of the next candidate at line parameter t (see photon_step):
     // (t * adm_q > 0) or adm_all.
     real adm_q;
+    // Kernels with FEAT_GUARD: no candidate within this distance of the photon (see
+    // landing_uncertainty); zero for a photon that does not sit on an element.
+    real guard;
     int32_t wid, wid0;
     int32_t mat;
     int32_t last_el;  // RayTrace.FirstEl, -1 none
@@ -542,6 +547,7 @@ __device__ __forceinline__ void set_admissibility_forward(Photon<real> &p)
 {
     p.flags &= ~F_ADM_ALL;
     p.adm_q = real(1);
+    p.guard = real(0);
 }
 
 template <typename real>
@@ -1043,26 +1049,50 @@ __device__ __forceinline__ void consider(Nearest<real> &best, bool inside, real 
 // photon's own position.  float64 takes the number as it stands.  float32
 // cannot (1e-8 cm is far below its resolution at these coordinates) and rejects
 // the element the photon sits on by index instead.  That leaves one case open:
-// a *different* element whose plane passes through the photon's position (a
-// detector lying flush on the interface just crossed): its line parameter is
-// the rounding residue of the last move, of either sign.  Scenes that contain
-// such elements (the host finds coplanar overlapping pairs) run kernels with
-// GUARD: a photon that sits on an element then accepts no plane within 8 units
-// in the last place of the numbers that went into its last move (its
-// coordinates and the length of the segment), measured perpendicular to the
-// plane for rectangles.  The guard is not free of side effects -- it also
-// hides a genuine next element that close to the photon, which on 2e7 photons
-// moved 400-800 of them to another fate where 50 differ between float32 and
-// float64 anyway -- so scenes without such elements do not use it.
+// a *different* element whose plane passes through the photon's position -- a
+// detector lying flush on the interface just crossed, or the neighbour across a
+// seam the photon has landed on: its line parameter is the rounding residue of
+// the last move, of either sign.  Scenes in which photons can get there (the
+// host finds coplanar overlapping pairs, and sources aimed at a seam) run
+// kernels with GUARD: a photon that sits on an element then accepts no plane
+// within the uncertainty of its own position, measured perpendicular to the
+// plane for rectangles.  The guard is not free of side effects -- it also hides
+// a genuine next element that close, where float64 still tells the two apart:
+// applied to every search of every scene it would send 3e-5 to 1e-4 of the
+// photons of the stacked-slab and rod scenes elsewhere than float64 does (3e-6
+// to 2e-5 without it), a bias that 1e10 photons resolve -- so scenes without
+// such elements do not use it.  A strict source aimed at a seam uses it until a
+// photon's first absorption: up to there every photon of such a source visits
+// the same landing points (only the reflect / cross decisions differ), so the
+// guard acts where one of these points lies on a seam and nowhere else.
+//
+// landing_uncertainty: how far the float32 landing point L' = L + t D, t = -off / (D.n), may lie
+// from the true one, along the old direction.  off = L.n - d0 carries two roundings at the size of
+// the coordinates, the reciprocal and the product one each at the size of the path, the sum one
+// more: at most 2^-24 (3 |coordinates| + 2 path) |D| / |D.n|; 4 units of (|coordinates| + path)
+// cover it.
+#ifndef RTMC_GUARD_UNITS
+#define RTMC_GUARD_UNITS 4.0
+#endif
+template <typename real>
+__device__ __forceinline__ real landing_uncertainty(const Photon<real> &p, real path, real dnorm, real dn)
+{
+    if constexpr (M<real>::has_self_hit_eps) {
+        return real(0);
+    } else {
+        const float reach = __builtin_fmaxf(__builtin_fmaxf(M<real>::abs(p.Lx), M<real>::abs(p.Ly)), M<real>::abs(p.Lz)) + path;
+        return reach * (float(RTMC_GUARD_UNITS / 16777216.0) * dnorm) * M<real>::abs(M<real>::rcp(dn));
+    }
+}
+
 template <bool GUARD, typename real>
-__device__ __forceinline__ real guard_distance(const Photon<real> &p, bool scene_wants_it)
+__device__ __forceinline__ real guard_distance(const Photon<real> &p, int scene_mode)
 {
     if constexpr (M<real>::has_self_hit_eps) {
         return real(1e-8);
     } else if constexpr (GUARD) {  // kernels that hold the code; the scene says whether it applies
-        const float reach = __builtin_fmaxf(__builtin_fmaxf(M<real>::abs(p.Lx), M<real>::abs(p.Ly)), M<real>::abs(p.Lz)) +
-                            __builtin_fminf(p.hitd, 1e30f);  // hitd is infinite after an iteration without a hit
-        return (scene_wants_it && (p.flags & F_WAS_EL)) ? reach * float(8.0 / 16777216.0) : 0.0f;
+        const bool applies = (scene_mode == 1) | ((scene_mode == 2) & ((p.flags & F_ABS_ONCE) == 0u));
+        return applies ? p.guard : real(0);
     } else {
         return real(0);
     }
@@ -1198,7 +1228,7 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
     dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
     const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
     const bool adm_all = (p.flags & F_ADM_ALL) != 0u;
-    const real guard = guard_distance<(FEATURES & FEAT_GUARD) != 0>(p, sc.use_guard != 0);
+    const real guard = guard_distance<(FEATURES & FEAT_GUARD) != 0>(p, sc.use_guard);
     const real guard_q = (M<real>::has_self_hit_eps || (FEATURES & FEAT_GUARD)) ? guard * M<real>::abs(p.adm_q) : real(0);
     Nearest<real> nearest;
     nearest.t = M<real>::inf();
@@ -1598,6 +1628,8 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
     } else {
         move_onto_plane(p, off, dn);
     }
+    // (a re-execution in place moves the photon by a rounding residue only)
+    if constexpr ((FEATURES & FEAT_GUARD) != 0) p.guard = landing_uncertainty(p, stale ? real(0) : p.hitd, dnorm, dn);
     if (type == RTMC_TYPE_DUMP) {  // Elements.py:152-169
         p.status = RTMC_ST_DUMPED;
         if (!DEFER_ENDINGS) finish_dumped<(FEATURES & FEAT_SPECTRA) != 0>(sc, lds, p, g, tally);

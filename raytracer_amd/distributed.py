@@ -66,6 +66,24 @@ def _tensor_device(d, device_index=None):
     return torch.device("cpu")
 
 
+def tally_payload_bytes(block):
+    """Size of the one message a rank contributes to the sum of the tallies."""
+    _, arrays = block
+    return 8 * (len(_abi.TALLY_SCALARS) + sum(arrays[k].size for k in list(_abi.TALLY_ARRAYS) + ["spectrum"]))
+
+
+def collective_info(block=None):
+    """What the exchange step of a run really saw: backend and number of ranks of the process
+    group (from torch.distributed itself, not from the command line), bytes per rank."""
+    d = _dist()
+    info = {"op": "all_reduce(sum) of the integer tallies, once per run",
+            "backend": None if d is None else str(d.get_backend()),
+            "world_size": 1 if d is None else int(d.get_world_size())}
+    if block is not None:
+        info["payload_bytes"] = int(tally_payload_bytes(block))
+    return info
+
+
 def allreduce_tallies(block, device_index=None):
     """Sum a (Tallies struct, arrays) block over all ranks, in place.
 

@@ -78,10 +78,49 @@ def _plane_batch(L, D, E, s):
     return b
 
 
-@pytest.mark.parametrize("precision,tol", [(_abi.F64, 1e-11), (_abi.F32, 2e-5)])
-def test_interface_and_lens_known_answers_as_batches(golden_dir, precision, tol):
+def _kat_conditions(k, ks):
+    """Condition numbers of the reference's 512 interface and 200 lens vectors, from their inputs
+    alone (the rule is stated in helpers.py)."""
+    L, D, S, N = k["if_L"], k["if_D"], k["if_S"], k["if_n"]
+    cos_i = np.abs(np.einsum("ij,ij->i", D, N)) / (H._norm(D) * H._norm(N))
+    n1, n2 = np.where(k["if_inside"], 1.5, 1.0), np.where(k["if_inside"], 1.0, 1.5)
+    sin2_t = (n1 / n2) ** 2 * (1.0 - cos_i ** 2)
+    with np.errstate(divide="ignore"):
+        k_refraction = 1.0 / np.sqrt(np.clip(1.0 - sin2_t, 0.0, None))   # infinite where no refracted ray exists
+    path = np.abs(np.einsum("ij,ij->i", S - L, N)) / (cos_i * H._norm(N))
+    c = {"cos_i": cos_i, "sin2_t": sin2_t, "refraction": k_refraction, "landing": H.kappa_landing(L, S, path, cos_i)}
+    # thin lens (PhotonObject.py:158-191): v = -(t2 D) - gz z^, t2 = (fo - nz gz) / (D.n)
+    L, D, S, N, f = ks["lens_L"], ks["lens_D"], ks["lens_S"], ks["lens_n"], ks["lens_f"]
+    dn = np.einsum("ij,ij->i", D, N)
+    cos_l = np.abs(dn) / (H._norm(D) * H._norm(N))
+    off = np.einsum("ij,ij->i", L - S, N)
+    B = L - (off / dn)[:, None] * D
+    gz = S[:, 2] - B[:, 2]
+    fo = np.where(np.sign(off) == np.sign(f), -f, f)
+    t2 = (fo - N[:, 2] * gz) / dn
+    v = -(t2[:, None] * D)
+    v[:, 2] -= gz
+    c["lens_landing"] = H.kappa_landing(L, S, np.abs(off) / cos_l, cos_l)
+    c["lens_direction"] = (np.abs(t2) * H._norm(D) / cos_l + c["lens_landing"]) / H._norm(v)
+    return c
+
+
+@pytest.mark.parametrize("precision", [_abi.F64, _abi.F32])
+def test_interface_and_lens_known_answers_as_batches(golden_dir, precision):
+    """All 512 interface and 200 lens vectors of the reference, none left out.  float64: 1e-11.
+    float32: every vector within 1e-6 times its own condition number (helpers.py states the
+    rule); the printed lines say how many also meet the plain 1e-6."""
     k = np.load(golden_dir + "/kat.npz")
     ks = np.load(golden_dir + "/kat_shapes.npz")
+    cond = _kat_conditions(k, ks)
+    f32 = precision == _abi.F32
+
+    def check(label, err, kappa):
+        if f32:
+            H.report_f32(label, err, kappa)
+        else:
+            assert np.max(err) < 1e-11, (label, np.max(err))
+
     photon = _standalone(Materials.MaterialObj("kat_air", 1.0))
     s = photon._scene()
     n = len(k["if_res"])
@@ -94,14 +133,12 @@ def test_interface_and_lens_known_answers_as_batches(golden_dir, precision, tol)
     # IsTotalReflect / Reflectance
     b = _plane_batch(k["if_L"], k["if_D"], k["if_E"], s)
     out = s.photon_op("reflectance", b, args, precision=precision)
-    near_critical = np.zeros(n, dtype=bool)
-    if precision == _abi.F32:       # within float32 rounding of the critical angle either answer is right
-        c = np.abs(np.einsum("ij,ij->i", k["if_D"], k["if_n"]))
-        near_critical = k["if_inside"] & (np.abs(c * c - (1 - 1 / 2.25)) < 1e-5)
-    assert np.array_equal(out[~near_critical, 0], k["if_res"][~near_critical, 0])
-    part = (k["if_res"][:, 0] == 0) & ~np.isnan(k["if_res"][:, 1]) & ~near_critical
-    assert np.abs(out[part, 1] - k["if_res"][part, 1]).max() < tol
-    if precision == _abi.F64:       # the reference's NaN reflectances are NaN here too
+    # (float32: the two answers meet where sin^2(theta_t) is 1 within its own rounding)
+    decided = np.abs(cond["sin2_t"] - 1.0) > (4 * H.F32_REL if f32 else 0.0)
+    assert np.array_equal(out[decided, 0], k["if_res"][decided, 0])
+    part = (k["if_res"][:, 0] == 0) & ~np.isnan(k["if_res"][:, 1]) & (out[:, 0] == 0)
+    check("reflectance", np.abs(out[part, 1] - k["if_res"][part, 1]), cond["refraction"][part])
+    if not f32:       # the reference's NaN reflectances are NaN here too
         assert np.array_equal(np.isnan(out[:, 1]), np.isnan(k["if_res"][:, 1]) & (k["if_res"][:, 0] == 0))
     # RefractOnPlane + PostProcessExecution
     b = _plane_batch(k["if_L"], k["if_D"], k["if_E"], s)
@@ -109,22 +146,21 @@ def test_interface_and_lens_known_answers_as_batches(golden_dir, precision, tol)
     s.photon_op("polarization", b, args, precision=precision)
     got = np.concatenate([b["loc"].T, b["dir"].T, b["efield"].T], axis=1)
     ref = k["if_res"][:, 3:12]
-    good = ~np.isnan(ref).any(axis=1)
+    good = ~np.isnan(ref).any(axis=1)       # no refracted ray beyond the critical angle: NaN in the reference
     assert np.isnan(got[~good, 3:6]).all()
-    # float32: a refracted ray close to grazing has lost digits in sqrt(1 - sin^2), and a ray that meets
-    # the plane at a shallow angle far away carries the rounding of D.n into its landing point
-    lim = 0.05 if precision == _abi.F32 else 0.0
-    graze = (np.abs(np.einsum("ij,ij->i", ref[:, 3:6], k["if_n"])) < lim) | \
-            (np.abs(np.einsum("ij,ij->i", k["if_D"], k["if_n"])) < lim)
-    scale = np.maximum(1.0, np.abs(ref))
-    assert (np.abs(got - ref) / scale)[good & ~graze].max() < tol
+    check("refraction: landing point", np.abs(got - ref)[good, 0:3].max(axis=1), cond["landing"][good])
+    check("refraction: direction", np.abs(got - ref)[good, 3:6].max(axis=1), cond["refraction"][good])
+    check("refraction: polarisation", np.abs(got - ref)[good, 6:9].max(axis=1),
+          (cond["refraction"] * H.kappa_rotation(k["if_D"], np.where(good[:, None], ref[:, 3:6], k["if_D"])))[good])
     # ReflectOnPlane + PostProcessExecution
     b = _plane_batch(k["if_L"], k["if_D"], k["if_E"], s)
     s.photon_op("reflect", b, args, precision=precision)
     s.photon_op("polarization", b, args, precision=precision)
     got = np.concatenate([b["loc"].T, b["dir"].T, b["efield"].T], axis=1)
-    scale = np.maximum(1.0, np.abs(k["if_refl"]))
-    assert (np.abs(got - k["if_refl"]) / scale)[~graze].max() < tol
+    ref = k["if_refl"]
+    check("reflection: landing point", np.abs(got - ref)[:, 0:3].max(axis=1), cond["landing"])
+    check("reflection: direction", np.abs(got - ref)[:, 3:6].max(axis=1), np.ones(n))
+    check("reflection: polarisation", np.abs(got - ref)[:, 6:9].max(axis=1), H.kappa_rotation(k["if_D"], ref[:, 3:6]))
     # FocusThinLens + PostProcessExecution
     m = len(ks["lens_f"])
     args = np.zeros((m, _abi.PHOP_ARGS))
@@ -133,10 +169,14 @@ def test_interface_and_lens_known_answers_as_batches(golden_dir, precision, tol)
     s.photon_op("lens", b, args, precision=precision)
     s.photon_op("polarization", b, args, precision=precision)
     got = np.concatenate([b["loc"].T, b["dir"].T, b["efield"].T], axis=1)
-    err = np.abs(got - ks["lens_res"])
-    scale = np.maximum(1.0, np.abs(ks["lens_res"]))
-    steep = np.abs(np.einsum("ij,ij->i", ks["lens_D"], ks["lens_n"])) >= lim
-    assert (err / scale)[steep].max() < tol * 10, (err / scale)[steep].max()
+    ref = ks["lens_res"]
+    if not f32:
+        assert np.abs(got - ref).max() < 1e-10   # (paths of up to 1e3 cm in this set)
+        return
+    check("lens: landing point", np.abs(got - ref)[:, 0:3].max(axis=1), cond["lens_landing"])
+    check("lens: direction", np.abs(got - ref)[:, 3:6].max(axis=1), cond["lens_direction"])
+    check("lens: polarisation", np.abs(got - ref)[:, 6:9].max(axis=1),
+          cond["lens_direction"] * H.kappa_rotation(ks["lens_D"], ref[:, 3:6]))
 
 
 @pytest.mark.parametrize("precision", [_abi.F64, _abi.F32])
@@ -240,12 +280,14 @@ def _stack(states, g, picks):
 
 
 @pytest.mark.parametrize("name", ["C2", "C3", "C4", "C6", "C7", "C8", "C9", "C2r"])
-@pytest.mark.parametrize("precision,tol", [(_abi.F64, 1e-10), (_abi.F32, 1e-5)])
-def test_search_absorption_and_execution_make_one_iteration(scenes, oracle_mod, name, precision, tol):
+@pytest.mark.parametrize("precision", [_abi.F64, _abi.F32])
+def test_search_absorption_and_execution_make_one_iteration(scenes, oracle_mod, name, precision):
     """CheckElementsForCrossingPoint, Photon.CheckForAbsorption and the element's
     ExecuteOperation called one after the other (RayTrace.py:178-189) against one
     iteration of rtmc_step_tape in the same precision, and in float64 against the CPU
-    checker's next state, with the reference's variates."""
+    checker's next state, with the reference's variates.  float64: 1e-10.  float32: the two
+    routes round differently, so they may differ by twice the bound each of them is held to
+    against the reference (1e-6 times the condition number of that photon's step, helpers.py)."""
     from test_gpu_parity import _oracle_states
     g = H.load_trace(name)
     rt, s = scenes(name)
@@ -287,13 +329,17 @@ def test_search_absorption_and_execution_make_one_iteration(scenes, oracle_mod, 
     for key in ("status", "material", "reflected", "was_element", "tape_pos"):
         assert np.array_equal(parts[key][cmp], whole[key][cmp]), key
     assert np.array_equal(parts["wavelength"][cmp], whole["wavelength"][cmp])
-    for key in ("loc", "dir", "efield"):
-        assert np.abs(parts[key][:, cmp] - whole[key][:, cmp]).max() < tol, key
+    if precision == _abi.F64:
+        bounds = np.full((len(picks), 3), 1e-10)
+    else:
+        bounds = 2.0 * np.array([H.f32_iteration_bounds(rt, states[i], states[i + 1], k) for i, k in picks])
+    for key, col in (("loc", 0), ("dir", 1), ("efield", 1)):
+        assert (np.abs(parts[key][:, cmp] - whole[key][:, cmp]).max(axis=0) <= bounds[cmp, col]).all(), key
     absorbing = np.array([s.packed.materials[m].IsAbsorber for m in whole["material"]])
     sel = cmp[absorbing[cmp] & (whole["dist_left"][cmp] < 1e30)]
     if len(sel):
         assert (np.abs(parts["dist_left"][sel] - whole["dist_left"][sel])
-                / np.maximum(1.0, np.abs(whole["dist_left"][sel]))).max() < tol
+                <= np.maximum(bounds[sel, 2], 1e-10 * np.abs(whole["dist_left"][sel]))).all()
     # bounces the elements counted = photons that stayed in their medium at a mirror or an interface
     kinds = np.array([rt.OpticalElements[e].Type.kind for e in el[idx]])
     reflected = (kinds == "Mirror") | ((kinds == "Interface") & (sub["reflected"] == 1))

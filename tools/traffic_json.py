@@ -13,7 +13,11 @@ for line in open(sys.argv[1]):
 # rocprofv3 reports both in KB; FETCH_SIZE is doubled (gfx950: the counter counts 64-byte
 # requests as 32-byte ones for reads)
 fetch_kb, write_kb = vals["FETCH_SIZE"], vals["WRITE_SIZE"]
+counters = {k: vals[k] for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32",
+                                 "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_SALU",
+                                 "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES") if k in vals}
 print(json.dumps({
+    **counters,
     "workload": sys.argv[3], "photons_per_launch": int(sys.argv[2]), "kernel": "trace_kernel<float, 0>",
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,

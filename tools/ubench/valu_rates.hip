@@ -88,6 +88,13 @@ k(uint32_t *out, uint32_t seed, unsigned long long *clk)
             } else if (OP == 20) {  // v_cmpx_le_f32 against an SGPR, mask restored once per four
                 asm volatile("s_mov_b64 s[10:11], exec\n v_cmpx_le_f32 vcc, |%0|, s12\n v_cmpx_le_f32 vcc, |%1|, s12\n v_cmpx_le_f32 vcc, |%2|, s12\n v_cmpx_le_f32 vcc, |%3|, s12\n s_mov_b64 exec, s[10:11]"
                              : : "v"(fa), "v"(fb), "v"(fc), "v"(fd) : "s10", "s11", "vcc");
+            } else if (OP >= 21 && OP <= 24) {  // v_fma_f32 under a partial execution mask: does the SIMD skip empty lane groups?
+                asm volatile("s_mov_b64 s[10:11], exec\n s_mov_b64 exec, %6\n"
+                             "v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5\n"
+                             "s_mov_b64 exec, s[10:11]"
+                             : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd) : "v"(1.0001f), "v"(0.25f),
+                               "s"(OP == 21 ? 0x00000000FFFFFFFFull : OP == 22 ? 0xFFFFull : OP == 23 ? 0x5555555555555555ull : 0xFFFFFFFFFFFFFFFFull)
+                             : "s10", "s11");
             } else if (OP == 8) {  // v_cmpx_le_f32 (writes EXEC) + restore
                 asm volatile("s_mov_b64 s[10:11], exec\n v_cmpx_le_f32 %0, %1\n v_cmpx_le_f32 %2, %3\n v_cmpx_le_f32 %0, %3\n v_cmpx_le_f32 %1, %2\n s_mov_b64 exec, s[10:11]"
                              : : "v"(fa), "v"(fb), "v"(fc), "v"(fd) : "s10", "s11");
@@ -159,6 +166,10 @@ int main()
     run<19>("v_sub_f32 with sgpr", out, n_cu, clk);
     run<20>("v_cmpx_le_f32 |v|, sgpr", out, n_cu, clk);
     run<7>("v_cndmask_b32 (vcc by s_mov)", out, n_cu, clk);
+    run<24>("v_fma_f32, exec all (+2 s_mov / 4)", out, n_cu, clk);
+    run<21>("v_fma_f32, exec low 32 lanes", out, n_cu, clk);
+    run<22>("v_fma_f32, exec low 16 lanes", out, n_cu, clk);
+    run<23>("v_fma_f32, exec every other lane", out, n_cu, clk);
     hipFree(out);
     return 0;
 }
