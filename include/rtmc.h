@@ -255,9 +255,12 @@ void rtmc_scene_destroy(rtmc_scene *scene);
 int rtmc_run(rtmc_scene *scene, int device, int precision, uint64_t seed,
              uint64_t first_photon, uint64_t n_photons, rtmc_tallies *out);
 
-/* rtmc_run for callers that cannot allocate: code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart
- * in the reference.  Same arguments, same kernels and bit-identical tallies as
+/* rtmc_run for callers that cannot allocate: tight serving loops, harnesses
+ * that forbid hipMalloc once they are running.  It has no counterpart in the
+ * reference.  Like rtmc_run it is synchronous: memsets, kernel and copy-back go
+ * to the scene's own stream and the call returns when the tallies are on the
+ * host, so it cannot become part of a HIP graph a caller is capturing on another
+ * stream.  Same arguments, same kernels and bit-identical tallies as
  * rtmc_run, but the device tally block and the work counter -- the only device
  * memory a trace needs beyond the resident scene -- live in a static array of
  * the library (65536 64-bit tally words + the counter, 516 KB on every GPU the

@@ -22,6 +22,7 @@ import weakref
 
 import numpy as np
 
+from . import RTUtils as RTU
 from . import _abi, configs
 
 SUN = "Sun spectrum AG15g"
@@ -137,8 +138,12 @@ class Photon:
         if geometric:            # the operation does not look at the wavelength
             b["wavelength"][0] = b["start_wavelength"][0] = sc.wavelengths()[0]
         else:
-            b["wavelength"][0] = self.Wavelength
-            b["start_wavelength"][0] = self.StartingWavelength
+            # the device knows the wavelengths a photon of this scene can carry (source lines and table
+            # rows); any other value -- the constructor's default on a photon that was never generated --
+            # is resolved to the nearest of them, as the reference's lookups would (PhotonObject.py:235,288)
+            known = np.sort(sc.wavelengths())
+            b["wavelength"][0] = known[RTU.FindClosestListElement(known, float(self.Wavelength))]
+            b["start_wavelength"][0] = known[RTU.FindClosestListElement(known, float(self.StartingWavelength))]
         b["dist_left"][0] = self.DistanceLeftToAbsorption
         b["psi"][0] = self.Psi
         mats = sc.packed.materials
@@ -254,15 +259,26 @@ class Photon:
     def CheckForAbsorption(self, OldPoint, SmallestDistance):
         """PhotonObject.py:206-264, pathway choice and re-emission included.  Which draws
         an absorption needs depends on what happens in it, so the device routine gets a
-        run of uniforms and turns them into the variates it needs."""
+        run of uniforms and turns them into the variates it needs.  The run is drawn from
+        numpy's global generator before the outcome is known: 256 values per call (a few are
+        used), so the generator moves on further than the reference's does; a chain of back
+        transfers or rejections that needs more is given a longer run of the same stream."""
         self.OldPoint = np.array(OldPoint, dtype=np.float64)
         sc = self._scene()
-        b = self._pack(sc)
-        b["hit_distance"][0] = SmallestDistance
-        tape = np.random.random_sample(256)
+        start = self._pack(sc)
+        start["hit_distance"][0] = SmallestDistance
         args = self._plane_args(point=self.PointCy)
-        sc.photon_op("absorption", b, args, tape, np.array([0, len(tape)], dtype=np.uint64),
-                     uniform_tape=True, device=self.Device, precision=self.Precision)
+        tape = np.random.random_sample(256)
+        while True:
+            b = {k: v.copy() for k, v in start.items()}
+            try:
+                sc.photon_op("absorption", b, args, tape, np.array([0, len(tape)], dtype=np.uint64),
+                             uniform_tape=True, device=self.Device, precision=self.Precision)
+                break
+            except _abi.RtmcError as err:
+                if "tape exhausted" not in str(err) or len(tape) >= 1 << 20:
+                    raise
+                tape = np.concatenate([tape, np.random.random_sample(3 * len(tape))])
         was_absorbed = int(b["status"][0]) != 0
         self._unpack(sc, b)
         if was_absorbed:

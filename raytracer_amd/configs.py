@@ -239,6 +239,41 @@ def strip_job(n_photons=10000, strips=14, sun=False):
     return job
 
 
+def tiled_floor_job(n_photons=10000, nx=7, ny=5):
+    """A floor of nx x ny detector tiles of unequal sizes in the plane z = 0 (tiles share their edges;
+    every third one is also covered by a larger detector listed after the tiles, which therefore
+    never counts where a tile lies), a mirror ceiling, four detector walls, a hemispherical source
+    above the floor: many rectangles in one plane, in two dimensions, with overlaps."""
+    els, props, sizes = [], [], []
+    xs = np.cumsum([0.0] + [0.5 + 0.25 * (i % 3) for i in range(nx)])
+    ys = np.cumsum([0.0] + [0.4 + 0.3 * (j % 2) for j in range(ny)])
+    xs, ys = xs - 0.5 * xs[-1], ys - 0.5 * ys[-1]
+    for j in range(ny):
+        for i in range(nx):
+            els.append([[0.5 * (xs[i] + xs[i + 1]), 0.5 * (ys[j] + ys[j + 1]), 0.0], [0.0, 0.0, 1.0]])
+            props.append([4, 0, 0, ""])
+            sizes.append([0.5 * (xs[i + 1] - xs[i]), 0.5 * (ys[j + 1] - ys[j])])
+    for k in range(0, nx * ny, 3):      # covers tile k and its surroundings
+        c = els[k][0]
+        els.append([[c[0] + 0.1, c[1] - 0.1, 0.0], [0.0, 0.0, 1.0]])
+        props.append([4, 0, 0, ""])
+        sizes.append([0.6, 0.6])
+    hx, hy = 0.5 * (xs[-1] - xs[0]), 0.5 * (ys[-1] - ys[0])
+    els.append([[0.0, 0.0, 2.0], [0.0, 0.0, 1.0]]); props.append([1]); sizes.append([hx + 1.0, hy + 1.0])
+    for sign in (1.0, -1.0):
+        els.append([[sign * (hx + 1.0), 0.0, 0.75], [sign, 0.0, 0.0]]); props.append([4, 0, 0, ""]); sizes.append([hy + 1.0, 1.25])
+        els.append([[0.0, sign * (hy + 1.0), 0.75], [0.0, sign, 0.0]]); props.append([4, 0, 0, ""]); sizes.append([hx + 1.0, 1.25])
+    els.append([[0.0, 0.0, -0.5], [0.0, 0.0, 1.0]]); props.append([4, 0, 0, ""]); sizes.append([hx + 1.0, hy + 1.0])
+    return {
+        "Elements": np.array(els, dtype=np.float64),
+        "ElementProperties": props,
+        "ElementGeometry": [1] * len(els),
+        "ElementSize": sizes,
+        "Materials": [copy.deepcopy(AIR_ROW)],
+        "Photon": _photon(n_photons, (0.1, -0.2, 1.0), ISOTROPIC, FIXED_WL, 460, "air", (0.0, 0.0, -1.0)),
+    }
+
+
 def flush_detector_job(n_photons=10000):
     """C2 plus a detector lying flush on the slab's top face (same plane, same
     footprint), listed after everything else.  In the reference the interface

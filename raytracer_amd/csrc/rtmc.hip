@@ -74,6 +74,8 @@ __device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char 
     l.guide = reinterpret_cast<const uint16_t *>(smem + sc.lay.guide);
     l.fx = reinterpret_cast<const uint32_t *>(smem + sc.lay.fx);
     l.bin = reinterpret_cast<const uint16_t *>(smem + sc.lay.bin);
+    l.run_cells = reinterpret_cast<const uint32_t *>(smem + sc.lay.run_cells);
+    l.run_members = reinterpret_cast<const RunMember<real> *>(smem + sc.lay.run_members);
     l.acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
     l.hist = reinterpret_cast<uint32_t *>(smem + sc.lay.hist);
     return l;
@@ -483,7 +485,7 @@ step_tape_kernel(const DevScene<real> *scene, SoaDev b, uint32_t n, uint32_t n_s
     else soa_load(b, k, lds, p);
     if (cross_el) {  // rtmc_op_crossing: the search only
         real dnorm;
-        const Nearest<real> nr = nearest_valid_hit<FEAT_ALL>(hot, p, dnorm);
+        const Nearest<real> nr = nearest_valid_hit<FEAT_ALL>(hot, lds, p, dnorm);
         const bool none = nr.e < 0;
         cross_el[k] = nr.e;
         cross_dist[k] = none ? __builtin_huge_val() : (double)(M<real>::abs(nr.t) * dnorm);
@@ -683,6 +685,7 @@ uint32_t threshold32(double q)
 }
 
 constexpr int MAX_ELEMENTS = 4096;  // beyond what the LDS holds; the real limit is the size of the LDS image
+constexpr size_t RUN_MIN_MEMBERS = 6;  // coplanar rectangles of one group from which on they are looked up as a run
 constexpr size_t MAX_FRAMES = 64;  // orthonormal frames besides which rectangles take the general test
 
 template <typename real>
@@ -690,6 +693,7 @@ struct DeviceImage {
     std::vector<DevElem<real>> elems;
     std::vector<HitChunk<real>> hits;
     int n_group[4];
+    bool has_runs = false;           // some axis group lists coplanar rectangles as runs (float32 only)
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
     DevSource<real> src;
@@ -771,11 +775,13 @@ struct rtmc_scene {
     bool has_coplanar = false;      // two elements overlap in one plane: the float32 kernels keep a guard distance
     bool seam_source = false;       // a strict source is aimed at a seam: guard distance until a photon's first absorption
     bool hist_in_hbm = false;       // detectors x bins too large for the LDS in some precision
+    bool has_runs = false;          // the float32 hit table lists coplanar rectangles as runs
     int features() const
     {
         if (has_area || has_coplanar || seam_source || hist_in_hbm) return FEAT_ALL;
         return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES | FEAT_FRAMES : 0) |
-               (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0);
+               (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0) |
+               (has_runs ? FEAT_RUNS : 0);
     }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
@@ -934,25 +940,140 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         }
     };
     img.hits.clear();
+    img.has_runs = false;
+    // float32: RUN_MIN_MEMBERS or more rectangles of a group that lie in one plane (the same p0, bit
+    // for bit) leave the group's list and follow it as a run (RunHdr): a grid over their bounding box
+    // whose cells name the members that touch them.  A member is entered into every cell its outline,
+    // widened by 1e-5 of the box, overlaps: the cell of a landing point is computed in float32 and
+    // may come out as a neighbour of the true one.  List order is kept among the records that stay
+    // and inside every cell.  A plane whose rectangles crowd more than RUN_CELL_SLOTS into one cell
+    // at every resolution tried stays in the list.
+    struct Run { RunHdr<real> hdr; };
+    std::vector<std::vector<Run>> runs(frames.size() * 3);
+    std::vector<uint32_t> run_cells;
+    std::vector<RunMember<real>> run_members;
+    auto build_run = [&](const std::vector<HitRec<real>> &members, Run &out) {
+        if (members.size() > 255) return false;
+        double lo[2] = {1e300, 1e300}, hi[2] = {-1e300, -1e300}, wmin[2] = {1e300, 1e300};
+        for (const HitRec<real> &m : members) {
+            const double c[2] = {(double)m.ci, (double)m.cj}, h[2] = {(double)m.hi, (double)m.hj};
+            for (int a = 0; a < 2; a++) {
+                lo[a] = std::min(lo[a], c[a] - h[a]); hi[a] = std::max(hi[a], c[a] + h[a]);
+                wmin[a] = std::min(wmin[a], 2 * h[a]);
+            }
+        }
+        if (!(wmin[0] > 0) || !(wmin[1] > 0)) return false;
+        // the resolution (cells per smallest member: 1, 2 or 4) whose fullest cell names the fewest
+        // members: a wave tries as many members as its fullest lane has to
+        int best_fill = RUN_CELL_SLOTS + 1, best_n[2] = {0, 0};
+        std::vector<uint32_t> best_cells;
+        double best_w[2] = {0, 0};
+        for (int refine = 1; refine <= 4; refine *= 2) {
+            int n[2];
+            double w[2], eps[2];
+            for (int a = 0; a < 2; a++) {
+                const double ext = hi[a] - lo[a];
+                n[a] = (int)std::min(255.0, std::max(1.0, std::ceil(ext / wmin[a] * refine - 1e-9)));
+                w[a] = ext / n[a];
+                eps[a] = 1e-5 * ext;
+            }
+            if ((size_t)n[0] * n[1] > 4096) break;
+            std::vector<uint32_t> cells((size_t)n[0] * n[1], 0xFFFFFFFFu);
+            std::vector<int> fill(cells.size(), 0);
+            bool ok = true;
+            for (size_t mi = 0; mi < members.size() && ok; mi++) {
+                const HitRec<real> &m = members[mi];
+                const double c[2] = {(double)m.ci, (double)m.cj}, h[2] = {(double)m.hi, (double)m.hj};
+                int first[2], last[2];
+                for (int a = 0; a < 2; a++) {
+                    first[a] = std::max(0, std::min(n[a] - 1, (int)std::floor((c[a] - h[a] - eps[a] - lo[a]) / w[a])));
+                    last[a] = std::max(0, std::min(n[a] - 1, (int)std::floor((c[a] + h[a] + eps[a] - lo[a]) / w[a])));
+                }
+                for (int cj = first[1]; cj <= last[1] && ok; cj++)
+                    for (int ci = first[0]; ci <= last[0] && ok; ci++) {
+                        const size_t cell = (size_t)cj * n[0] + ci;
+                        if (fill[cell] == RUN_CELL_SLOTS) { ok = false; break; }
+                        cells[cell] = (cells[cell] & ~(0xFFu << (8 * fill[cell]))) | ((uint32_t)mi << (8 * fill[cell]));
+                        fill[cell]++;
+                    }
+            }
+            if (!ok) continue;
+            const int fullest = *std::max_element(fill.begin(), fill.end());
+            if (fullest < best_fill) {
+                best_fill = fullest; best_cells.swap(cells);
+                for (int a = 0; a < 2; a++) { best_n[a] = n[a]; best_w[a] = w[a]; }
+            }
+        }
+        if (best_cells.empty()) return false;
+        memset(&out.hdr, 0, sizeof out.hdr);
+        out.hdr.p0 = members[0].p0;
+        out.hdr.gi0 = (real)lo[0]; out.hdr.gj0 = (real)lo[1];
+        out.hdr.inv_wi = (real)(1.0 / best_w[0]); out.hdr.inv_wj = (real)(1.0 / best_w[1]);
+        out.hdr.ni_1 = best_n[0] - 1; out.hdr.nj_1 = best_n[1] - 1;
+        out.hdr.cell_off = (int32_t)run_cells.size();
+        out.hdr.mem_off = (int32_t)run_members.size();
+        run_cells.insert(run_cells.end(), best_cells.begin(), best_cells.end());
+        for (const HitRec<real> &m : members) {
+            RunMember<real> rm;
+            memset(&rm, 0, sizeof rm);
+            rm.ci = m.ci; rm.cj = m.cj; rm.hi = m.hi; rm.hj = m.hj; rm.index = m.index;
+            run_members.push_back(rm);
+        }
+        return true;
+    };
+    if (sizeof(real) == 4 && !getenv("RTMC_NO_RUNS")) {
+        for (size_t fi = 0; fi < frames.size(); fi++)
+            for (int k = 0; k < 3; k++) {
+                std::vector<HitRec<real>> &recs = frames[fi].group[k], stay;
+                std::vector<Run> &rs = runs[fi * 3 + k];
+                std::vector<real> planes_done;
+                for (const HitRec<real> &h : recs) {
+                    if (std::find(planes_done.begin(), planes_done.end(), h.p0) != planes_done.end()) continue;
+                    planes_done.push_back(h.p0);
+                    std::vector<HitRec<real>> members;
+                    for (const HitRec<real> &o : recs)
+                        if (o.p0 == h.p0) members.push_back(o);
+                    Run r;
+                    if (members.size() >= RUN_MIN_MEMBERS && rs.size() < 32767 && build_run(members, r)) rs.push_back(r);
+                    else planes_done.back() = h.p0, stay.insert(stay.end(), members.begin(), members.end());
+                }
+                // (the records that stay: back into list order)
+                std::sort(stay.begin(), stay.end(), [](const HitRec<real> &a, const HitRec<real> &b) { return a.index < b.index; });
+                if (stay.size() / HIT_CHUNK + 1 > 65535) { rs.clear(); continue; }  // (counts are 16-bit halves)
+                recs.swap(stay);
+                if (!rs.empty()) img.has_runs = true;
+            }
+    }
+    auto group_count = [&](size_t fi, int k) {
+        return (int)(frames[fi].group[k].size() / HIT_CHUNK) | ((int)runs[fi * 3 + k].size() << 16);
+    };
+    auto emit_runs = [&](std::vector<Run> &rs) {
+        for (Run &r : rs) {
+            HitChunk<real> raw;
+            static_assert(sizeof(RunHdr<real>) == sizeof(HitChunk<real>), "header = one chunk");
+            memcpy(&raw, &r.hdr, sizeof raw);
+            img.hits.push_back(raw);
+        }
+    };
     int extra_frames = 0;
     for (size_t fi = 0; fi < frames.size(); fi++) {
         Frame &f = frames[fi];
         for (int k = 0; k < 3; k++) pad(f.group[k]);
         if (fi == 0) {
-            for (int k = 0; k < 3; k++) img.n_group[k] = (int)(f.group[k].size() / HIT_CHUNK);
+            for (int k = 0; k < 3; k++) img.n_group[k] = group_count(fi, k);
         } else {
             static_assert(sizeof(FrameHdr<real>) == sizeof(HitChunk<real>), "header = one chunk");
             FrameHdr<real> hdr;
             memset(&hdr, 0, sizeof hdr);
             for (int a = 0; a < 3; a++)
                 for (int c = 0; c < 3; c++) hdr.R[3 * a + c] = (real)f.r[a][c];
-            for (int k = 0; k < 3; k++) hdr.n[k] = (int)(f.group[k].size() / HIT_CHUNK);
+            for (int k = 0; k < 3; k++) hdr.n[k] = group_count(fi, k);
             HitChunk<real> raw;
             memcpy(&raw, &hdr, sizeof raw);
             img.hits.push_back(raw);
             extra_frames++;
         }
-        for (int k = 0; k < 3; k++) emit(f.group[k]);
+        for (int k = 0; k < 3; k++) { emit(f.group[k]); emit_runs(runs[fi * 3 + k]); }
     }
     pad(general);
     emit(general);
@@ -1055,6 +1176,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.guide = (uint32_t)off; off = align(off + 2 * guide.size());
     lay.fx = (uint32_t)off; off = align(off + 4 * energy_fx.size());
     lay.bin = (uint32_t)off; off = align(off + 2 * wid_cbin.size());
+    lay.run_cells = (uint32_t)off; off = align(off + 4 * run_cells.size());
+    lay.run_members = (uint32_t)off; off = align(off + sizeof(RunMember<real>) * run_members.size());
     lay.acc = (uint32_t)off;
     lay.n_wid = (uint32_t)n_wid;
     lay.n_bins = (uint32_t)n_bins;
@@ -1077,6 +1200,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     memcpy(img.lds.data() + lay.guide, guide.data(), 2 * guide.size());
     memcpy(img.lds.data() + lay.fx, energy_fx.data(), 4 * energy_fx.size());
     memcpy(img.lds.data() + lay.bin, wid_cbin.data(), 2 * wid_cbin.size());
+    if (!run_cells.empty()) memcpy(img.lds.data() + lay.run_cells, run_cells.data(), 4 * run_cells.size());
+    if (!run_members.empty()) memcpy(img.lds.data() + lay.run_members, run_members.data(), sizeof(RunMember<real>) * run_members.size());
 
     const rtmc_source &s = d->source;
     DevSource<real> &o = img.src;
@@ -1381,6 +1506,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
     s->has_frames = (s->img32.n_group[3] >> 16) != 0;
+    s->has_runs = s->img32.has_runs;
     s->hist_in_hbm = s->img32.lay.hist_in_hbm || s->img64.lay.hist_in_hbm;
     if (s->img32.lay.total > 160 * 1024) {
         size_t need = s->img32.lay.total;
@@ -1445,8 +1571,17 @@ static const void *trace_function(int features)
 {
     if (features & (FEAT_AREA | FEAT_GUARD | FEAT_HBMHIST)) return (const void *)trace_kernel<real, FEAT_ALL>;
     if constexpr (sizeof(real) == 8) {
-        return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);
+        return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);   // (float64 tables hold no runs)
     } else {
+        if (features & FEAT_RUNS) {  // runs: the rectangle-only kernels of the world frame, else the one with everything
+            if (features & (FEAT_ALIGNED | FEAT_SHAPES | FEAT_FRAMES)) return (const void *)trace_kernel<real, FEAT_ALL>;
+            switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+            case 0: return (const void *)trace_kernel<real, FEAT_RUNS>;
+            case FEAT_SPECTRA: return (const void *)trace_kernel<real, FEAT_RUNS | FEAT_SPECTRA>;
+            case FEAT_BACK: return (const void *)trace_kernel<real, FEAT_RUNS | FEAT_BACK>;
+            default: return (const void *)trace_kernel<real, FEAT_RUNS | FEAT_SPECTRA | FEAT_BACK>;
+            }
+        }
         switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
         case 0: return trace_variant<real, 0>(features);
         case FEAT_SPECTRA: return trace_variant<real, FEAT_SPECTRA>(features);
@@ -1528,9 +1663,13 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     p.n_cu = prop.multiProcessorCount;
     const void *trace32 = trace_function<float>(s->features());
     const void *trace64 = trace_function<double>(s->features());
-    HIP_TRY(hipFuncSetAttribute(trace32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
-    HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
-    HIP_TRY(hipFuncSetAttribute((const void *)photon_op_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img32.lay.total));
+    // The attribute belongs to the function, not to the scene: every scene of the process shares
+    // these kernels, so each is allowed the whole LDS of a CU once and for all (a later, smaller
+    // scene must not lower the limit under an earlier, larger one).
+    const int lds_limit = 160 * 1024;
+    for (const void *fn : {trace32, trace64, (const void *)step_tape_kernel<float>, (const void *)photon_op_kernel<float>,
+                           (const void *)step_tape_kernel<double>, (const void *)photon_op_kernel<double>})
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
     {  // the workgroup size that puts the most waves on a SIMD; the smaller one on a tie
         int best_waves = -1;
         for (int block = TRACE_BLOCK; block <= TRACE_BLOCK_MAX; block += 256) {
@@ -1546,12 +1685,8 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
             }
         }
     }
-    if (s->img64.lay.total <= 160 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(trace64, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
-        HIP_TRY(hipFuncSetAttribute((const void *)step_tape_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
-        HIP_TRY(hipFuncSetAttribute((const void *)photon_op_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->img64.lay.total));
+    if (s->img64.lay.total <= (size_t)lds_limit)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&p.max_blocks64, trace64, TRACE_BLOCK, s->img64.lay.total));
-    }
     if (s->hist_in_hbm) {  // one private histogram per workgroup that can be resident, in either precision
         p.private_hist_copies = (size_t)p.n_cu * (size_t)std::max(1, std::max(p.max_blocks32, p.max_blocks64));
         const size_t words = (size_t)std::max(1, s->n_dump) * s->bins_used.size();
@@ -1775,8 +1910,8 @@ RTMC_API int rtmc_run(rtmc_scene *s, int device, int precision, uint64_t seed, u
     });
 }
 
-RTMC_API int rtmc_run_noalloc(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
-                                uint64_t n_photons, rtmc_tallies *out)
+static int run_noalloc_impl(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                            uint64_t n_photons, rtmc_tallies *out)
 {
     int rc = check_run_arguments(s, precision, first_photon, n_photons, out);
     if (rc) return rc;
@@ -1792,7 +1927,11 @@ RTMC_API int rtmc_run_noalloc(rtmc_scene *s, int device, int precision, uint64_t
         auto it = s->dev.find(device);  // never inserts
         if (it != s->dev.end() && it->second.ready) pp = &it->second;
     }
-    unsigned long long *const base = g_gpu[device].scratch_ptr;
+    unsigned long long *base = nullptr;
+    {   // (another thread may be uploading its first scene to this GPU right now)
+        std::lock_guard<std::mutex> lock(g_gpu_setup_mu);
+        base = g_gpu[device].scratch_ptr;
+    }
     if (!pp || !base)
         return fail(RTMC_EINVAL, "scene is not resident on device %d: rtmc_run (for zero photons, if nothing is to be "
                                  "traced yet) uploads it, rtmc_run_noalloc never allocates", device);
@@ -1810,6 +1949,14 @@ RTMC_API int rtmc_run_noalloc(rtmc_scene *s, int device, int precision, uint64_t
     }
     if (n_photons) set_last_kernel_ms(s, *pp, ms);
     return RTMC_OK;
+}
+
+RTMC_API int rtmc_run_noalloc(rtmc_scene *s, int device, int precision, uint64_t seed, uint64_t first_photon,
+                                uint64_t n_photons, rtmc_tallies *out)
+{
+    // (nothing in the body allocates, so nothing in it throws; the wrapper keeps the rule that no entry
+    // point lets anything propagate)
+    return guarded([&] { return run_noalloc_impl(s, device, precision, seed, first_photon, n_photons, out); });
 }
 
 RTMC_API double rtmc_last_kernel_ms(const rtmc_scene *s, int device)

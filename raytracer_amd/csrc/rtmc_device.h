@@ -91,6 +91,39 @@ struct alignas(64) FrameHdr {
 static_assert(sizeof(FrameHdr<float>) == sizeof(HitChunk<float>) && sizeof(FrameHdr<double>) == sizeof(HitChunk<double>),
               "a frame header takes the place of one chunk");
 
+// Many rectangles of one axis group in one plane (a segmented read-out along an edge, the side
+// faces of a tall stack): the plane is intersected once and the rectangles that can contain the
+// landing point are looked up instead of being tried one after the other.  Such a *run* has a
+// header in the hit table behind the other records of its group (the group's count holds the chunks
+// of those in its low half and the number of runs in its high half) and, in the LDS image, a grid of
+// cells over the members' bounding box in the plane: a cell names the (at most four) members that
+// touch it, in list order.  Float32 tables only.
+template <typename real>
+struct alignas(64) RunHdr {
+    real p0;                  // the plane
+    real gi0, gj0;            // corner of the grid (in-plane coordinates i, j)
+    real inv_wi, inv_wj;      // 1 / cell size
+    int32_t ni_1, nj_1;       // cells along i and j, minus one
+    int32_t cell_off;         // first cell word of this run (index into Lds::run_cells)
+    int32_t mem_off;          // first member record (index into Lds::run_members)
+    int32_t pad[7];
+};
+static_assert(sizeof(RunHdr<float>) == sizeof(HitChunk<float>), "a run header takes the place of one chunk");
+// the part of the header the search reads
+template <typename real>
+struct RunHead {
+    real p0, gi0, gj0, inv_wi, inv_wj;
+    int32_t ni_1, nj_1, cell_off, mem_off;
+};
+// A member of a run as the lanes gather it from LDS.
+template <typename real>
+struct alignas(16) RunMember {
+    real ci, cj, hi, hj;
+    int32_t index;
+    int32_t pad[3];
+};
+constexpr int RUN_CELL_SLOTS = 4;       // members a cell can name (one byte each, 0xFF = none)
+
 // One medium.
 template <typename real>
 struct DevMat {
@@ -141,7 +174,7 @@ struct DevSource {
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, acc, hist, total;
+    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, acc, hist, total;
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
@@ -216,12 +249,15 @@ struct HotScene {
 // table then holds frame headers and the search a loop over them); kernels
 // with FEAT_SHAPES always have it.
 // FEAT_GUARD (float32; only instantiated together with everything else): see guard_distance.
+// FEAT_RUNS (float32): some axis group holds three or more rectangles in one plane (the edge faces of
+// stacked slabs, a segmented read-out); the hit table then lists them as runs behind the plane they
+// share, see RunHdr.
 // FEAT_HBMHIST (only with everything else): detectors x wavelength bins exceed what the LDS
 // can hold beside the tables; every workgroup then counts hits with atomics in a histogram of
 // its own in HBM (one shared histogram is bounded by the rate of atomics on its few hot
 // words: 2e9 photons/s whatever the scene) and a second kernel adds the copies up.
 enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_BACK = 16, FEAT_FRAMES = 32, FEAT_GUARD = 64,
-             FEAT_HBMHIST = 128, FEAT_ALL = 255 };
+             FEAT_HBMHIST = 128, FEAT_RUNS = 256, FEAT_ALL = 511 };
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -424,6 +460,8 @@ struct Lds {
     const uint16_t *guide;  // per threshold table GUIDE_BUCKETS + 1 entries: thresholds below bucket b's first value
     const uint32_t *fx;    // per wavelength id: llrint(wl_source / wl * 2^24) for a single-line source
     const uint16_t *bin;   // per wavelength id: compact detector bin
+    const uint32_t *run_cells;              // grids of the runs of coplanar rectangles
+    const RunMember<real> *run_members;     // their members
     unsigned long long *acc;
     uint32_t *hist;
 };
@@ -1154,16 +1192,59 @@ __device__ __forceinline__ void consider_pair_f32(Nearest<float> &best, const Hi
                  : "vcc");
 }
 
+// The runs of one axis group (float32): one plane intersection per run, then the members named by
+// the grid cell the landing point falls into, gathered per lane from LDS and tried in list order
+// (strict "nearer": the first member that contains the point keeps it).  Candidates of different
+// planes of one group cannot tie -- their line parameters differ -- unless both directions along
+// the line are admissible and the photon sits exactly midway (`ties_possible`: some lane of the
+// wave accepts every candidate); only then is every run folded into the group's result with the
+// index rule.
+__device__ __forceinline__ void scan_runs_f32(const HitChunk<float> *table, const Lds<float> &lds, uint32_t &offset, int n_runs,
+                                              float inv_dk, float m_lk, float Li, float Di, float Lj, float Dj, float adm_q,
+                                              float adm_bias, int skip, bool ties_possible, Nearest<float> &g)
+{
+    for (; n_runs != 0; n_runs--) {
+        const RunHead<float> h = load_uniform_at(reinterpret_cast<const RunHead<float> *>(table), offset);
+        offset += (uint32_t)sizeof(RunHdr<float>);
+        const float t = h.p0 * inv_dk + m_lk;
+        const float Bi = Li + t * Di, Bj = Lj + t * Dj;
+        // cell of the landing point (a point outside the grid is tried against an edge cell's members and fails)
+        const int ci = __builtin_amdgcn_fmed3f(__builtin_floorf((Bi - h.gi0) * h.inv_wi), 0.0f, (float)h.ni_1);
+        const int cj = __builtin_amdgcn_fmed3f(__builtin_floorf((Bj - h.gj0) * h.inv_wj), 0.0f, (float)h.nj_1);
+        // (NaN coordinates -- a line parallel to the plane -- give cell 0 and fail the tests below)
+        uint32_t word = lds.run_cells[h.cell_off + mul24(cj, h.ni_1 + 1) + ci];
+        const bool candidate = (t * adm_q + adm_bias > 0.0f) & (ties_possible ? true : M<float>::abs(t) < M<float>::abs(g.t));
+        word = candidate ? word : 0xFFFFFFFFu;
+        Nearest<float> r;
+        r.t = ties_possible ? M<float>::inf() : g.t;
+        r.e = ties_possible ? -1 : g.e;
+        while (__ballot((word & 0xFFu) != 0xFFu) != 0ull) {
+            const uint32_t slot = word & 0xFFu;
+            word = (word >> 8) | 0xFF000000u;
+            if (slot != 0xFFu) {
+                const RunMember<float> &m = row(lds.run_members, h.mem_off + (int)slot);
+                const bool ok = (M<float>::abs(Bi - m.ci) <= m.hi) & (M<float>::abs(Bj - m.cj) <= m.hj) & (m.index != skip) &
+                                (M<float>::abs(t) < M<float>::abs(r.t));
+                r.t = ok ? t : r.t;
+                r.e = ok ? m.index : r.e;
+            }
+        }
+        if (ties_possible) merge_nearest(g, r);
+        else g = r;
+    }
+}
+
 // One group of rectangles normal to axis k of the current frame, one chunk of
 // records per scalar fetch; the group's nearest candidate is then folded into
 // the overall best.
-template <typename real>
-__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *table, uint32_t &offset, int count, real Lk,
+template <bool RUNS, typename real>
+__device__ __forceinline__ void scan_axis_group(const HitChunk<real> *table, const Lds<real> &lds, uint32_t &offset, int packed_count, real Lk,
                                                 real Dk, real Li, real Di, real Lj, real Dj, real adm_q,
                                                 bool adm_all, real guard_q, int skip, real dnorm, real guard,
-                                                Nearest<real> &best, bool first = false)
+                                                bool ties_possible, Nearest<real> &best, bool first = false)
 {
-    if (count == 0) return;
+    if (packed_count == 0) return;
+    const int count = RUNS ? (packed_count & 0xFFFF) : packed_count;
     const real inv_dk = M<real>::rcp(Dk), m_lk = -Lk * inv_dk;
     // adm_q is zero when adm_all is set; guard_q = guard * |adm_q| and a plane at
     // line parameter t lies |t D_k| away from the photon
@@ -1193,20 +1274,22 @@ __device__ __forceinline__ void scan_axis_group(const HitChunk<real> *table, uin
             }
         }
     }
+    if constexpr (RUNS && sizeof(real) == 4 && !M<real>::has_self_hit_eps)
+        scan_runs_f32(table, lds, offset, packed_count >> 16, inv_dk, m_lk, Li, Di, Lj, Dj, adm_q, adm_bias, skip, ties_possible, g);
     if (direct) best = g;
     else merge_nearest(best, g);
 }
 
 // The three axis groups of one frame; (L, D) is the line in that frame.
-template <typename real>
-__device__ __forceinline__ void scan_frame(const HitChunk<real> *table, uint32_t &offset, int n0, int n1, int n2,
+template <bool RUNS, typename real>
+__device__ __forceinline__ void scan_frame(const HitChunk<real> *table, const Lds<real> &lds, uint32_t &offset, int n0, int n1, int n2,
                                            real Lx, real Ly, real Lz, real Dx, real Dy, real Dz, real adm_q,
                                            bool adm_all, real guard_q, int skip, real dnorm, real guard,
-                                           Nearest<real> &best, bool first = false)
+                                           bool ties_possible, Nearest<real> &best, bool first = false)
 {
-    scan_axis_group(table, offset, n0, Lx, Dx, Ly, Dy, Lz, Dz, adm_q, adm_all, guard_q, skip, dnorm, guard, best, first);
-    scan_axis_group(table, offset, n1, Ly, Dy, Lz, Dz, Lx, Dx, adm_q, adm_all, guard_q, skip, dnorm, guard, best);
-    scan_axis_group(table, offset, n2, Lz, Dz, Lx, Dx, Ly, Dy, adm_q, adm_all, guard_q, skip, dnorm, guard, best);
+    scan_axis_group<RUNS>(table, lds, offset, n0, Lx, Dx, Ly, Dy, Lz, Dz, adm_q, adm_all, guard_q, skip, dnorm, guard, ties_possible, best, first);
+    scan_axis_group<RUNS>(table, lds, offset, n1, Ly, Dy, Lz, Dz, Lx, Dx, adm_q, adm_all, guard_q, skip, dnorm, guard, ties_possible, best);
+    scan_axis_group<RUNS>(table, lds, offset, n2, Lz, Dz, Lx, Dx, Ly, Dy, adm_q, adm_all, guard_q, skip, dnorm, guard, ties_possible, best);
 }
 
 // RayTrace.py:120-154 CheckElementsForCrossingPoint: the nearest element whose
@@ -1222,7 +1305,7 @@ __device__ __forceinline__ void scan_frame(const HitChunk<real> *table, uint32_t
 // then for every further frame a header (rotation, group sizes) and its three
 // groups in the frame's coordinates, then the elements tested on their full record.
 template <int FEATURES, typename real>
-__device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> &sc, const Photon<real> &p, real &dnorm)
+__device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> &sc, const Lds<real> &lds, const Photon<real> &p, real &dnorm)
 {
     constexpr bool SHAPES = (FEATURES & FEAT_SHAPES) != 0;
     dnorm = M<real>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
@@ -1234,8 +1317,10 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
     nearest.t = M<real>::inf();
     nearest.e = -1;
     uint32_t offset = 0;  // bytes into the hit table
-    scan_frame(sc.hits, offset, sc.n_group[0], sc.n_group[1], sc.n_group[2], p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz,
-               p.adm_q, adm_all, guard_q, skip, dnorm, guard, nearest, true);
+    constexpr bool RUNS = (FEATURES & FEAT_RUNS) != 0;
+    const bool ties_possible = RUNS ? __ballot(adm_all) != 0ull : false;
+    scan_frame<RUNS>(sc.hits, lds, offset, sc.n_group[0], sc.n_group[1], sc.n_group[2], p.Lx, p.Ly, p.Lz, p.Dx, p.Dy, p.Dz,
+                     p.adm_q, adm_all, guard_q, skip, dnorm, guard, ties_possible, nearest, true);
     const int n_general = (FEATURES & FEAT_FRAMES) ? (sc.n_group[3] & 0xFFFF) : sc.n_group[3];
     for (int frames = (FEATURES & FEAT_FRAMES) ? (sc.n_group[3] >> 16) : 0; frames != 0; frames--) {
         const FrameHdr<real> f = load_uniform_at(reinterpret_cast<const FrameHdr<real> *>(sc.hits), offset);
@@ -1244,8 +1329,8 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
                    Lz = f.R[6] * p.Lx + f.R[7] * p.Ly + f.R[8] * p.Lz;
         const real Dx = f.R[0] * p.Dx + f.R[1] * p.Dy + f.R[2] * p.Dz, Dy = f.R[3] * p.Dx + f.R[4] * p.Dy + f.R[5] * p.Dz,
                    Dz = f.R[6] * p.Dx + f.R[7] * p.Dy + f.R[8] * p.Dz;
-        scan_frame(sc.hits, offset, f.n[0], f.n[1], f.n[2], Lx, Ly, Lz, Dx, Dy, Dz, p.adm_q, adm_all, guard_q, skip,
-                   dnorm, guard, nearest);
+        scan_frame<RUNS>(sc.hits, lds, offset, f.n[0], f.n[1], f.n[2], Lx, Ly, Lz, Dx, Dy, Dz, p.adm_q, adm_all, guard_q, skip,
+                         dnorm, guard, ties_possible, nearest);
     }
     const uint32_t end = offset + (uint32_t)n_general * (uint32_t)sizeof(HitChunk<real>);
     for (; offset != end; offset += (uint32_t)sizeof(HitChunk<real>)) {
@@ -1705,7 +1790,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     g.block((uint32_t)p.iter, BLK_STEP);
     tally.stamp(0);
     real dnorm;
-    const Nearest<real> nearest = nearest_valid_hit<FEATURES>(sc, p, dnorm);
+    const Nearest<real> nearest = nearest_valid_hit<FEATURES>(sc, lds, p, dnorm);
     tally.stamp(1);
     const real best_t = nearest.t;
     const int best_e = nearest.e;

@@ -388,3 +388,22 @@ def test_hand_stepped_photon_reproduces_the_tallies_of_a_run():
     assert abs(converted / n - p_ic) < 5 * np.sqrt(p_ic * (1 - p_ic) / n), (converted, p_ic)
     counted = sum(oe.Type.Counter for oe in rt.OpticalElements if oe.Type.kind == "Dump")
     assert counted == dumped == n - converted
+
+
+def test_hand_driven_photon_with_an_unknown_wavelength():
+    """A photon that was never generated keeps the constructor's 450 nm (PhotonObject.py:19), which is
+    no wavelength of the scene: the reference resolves it with FindClosestListElement
+    (PhotonObject.py:235,288), and so do LamBeerDistance and CheckForAbsorption here."""
+    rt = H.raytrace_for("C2")
+    ph = rt.Photon
+    ph.Wavelength = ph.StartingWavelength = 450.0
+    ph.CurrentMaterial = next(m for m in rt.MaterialDict.values() if m.IsAbsorber)
+    ph.Location, ph.Direction = np.array([0.0, 0.0, 0.1]), np.array([0.0, 0.0, 1.0])
+    ph.ElectricFieldVector = np.array([1.0, 0.0, 0.0])
+    np.random.seed(4)
+    ph.LamBeerDistance()
+    assert 0.0 < ph.DistanceLeftToAbsorption < 10.0
+    ph.PointCy = np.array([0.0, 0.0, 0.3])
+    ph.DistanceLeftToAbsorption = 0.05
+    ph.CheckForAbsorption(ph.Location, 0.2)
+    assert ph.Status in ("ReemittedAcceptor", "InternalConverted") and ph.Location[2] == pytest.approx(0.15)

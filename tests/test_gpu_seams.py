@@ -262,3 +262,44 @@ def test_strict_sources_aimed_at_a_seam(oracle_mod):
         finally:
             s.close()
     assert compared["f32"] >= 4 and compared["f64"] >= 4, compared
+
+
+@pytest.mark.parametrize("job", ["strips", "floor", "stack"])
+def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, job):
+    """Six or more rectangles of one plane are looked up through a grid instead of being tried one by
+    one (float32 hit table).  The same scenes built with that switched off (RTMC_NO_RUNS) give the same
+    integers, photon for photon -- the segmented edge read-out, a floor of 35 unequal tiles partly
+    covered by larger detectors of the same plane (list order decides, RayTrace.py:134), a stack of
+    eight slabs whose side faces share four planes -- and float64 agrees with the checker."""
+    def build():
+        rt = RayTrace.RayTrace(demo_scene=False)
+        if job == "strips":
+            rt.LoadJob(configs.strip_job(10, strips=30))
+        elif job == "floor":
+            rt.LoadJob(configs.tiled_floor_job(10))
+        else:
+            rt.LoadJob(configs.stacked_job(10, n_slabs=8))
+        return rt, rt.Scene()
+    n = 400000
+    rt, with_runs = build()
+    monkeypatch.setenv("RTMC_NO_RUNS", "1")
+    _, without = build()
+    monkeypatch.delenv("RTMC_NO_RUNS")
+    try:
+        a, b = with_runs.run(n, seed=31), without.run(n, seed=31)
+        for key in ("counter", "spectral", "bounce", "energy_fx", "spectrum"):
+            assert np.array_equal(a[key], b[key]), key
+        for key in _abi.TALLY_SCALARS:
+            assert a[key] == b[key], key
+        assert a["n_photons"] == n and a["n_lost"] == 0
+        if job == "floor":      # the covering detectors count only beside the tiles
+            tiles = int(a["counter"][:35].sum())
+            assert tiles > 0.4 * n and 0 < int(a["counter"][35:47].sum()) < 0.1 * n
+        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(100000, seed=32, threads=8)
+        g64 = with_runs.run(100000, seed=32, precision=_abi.F64)
+        moved = int(np.abs(g64["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum())
+        g32 = with_runs.run(100000, seed=32)
+        moved32 = int(np.abs(g32["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum())
+        assert moved <= 8 and moved32 <= 40, (moved, moved32)
+    finally:
+        with_runs.close(), without.close()

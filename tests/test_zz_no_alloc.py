@@ -15,6 +15,15 @@ pytestmark = pytest.mark.gpu
 KEYS = ("counter", "spectral", "bounce", "energy_fx", "spectrum")
 
 
+def _free_device_bytes():
+    """hipMemGetInfo of the current device, straight from the HIP runtime."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
 def _same(a, b):
     for key in KEYS:
         assert np.array_equal(a[key], b[key]), key
@@ -32,6 +41,11 @@ def test_noalloc_equals_rtmc_run_twice_in_a_row():
         s.run(0, seed=3)                       # uploads the scene
         big = s.run(300000, seed=3, noalloc=True)
         small = s.run(1000, seed=3, first_photon=12345, noalloc=True)
+        # a warm call leaves the device's free memory where it was: nothing was allocated (or freed)
+        before = _free_device_bytes()
+        again = s.run(1000, seed=3, first_photon=12345, noalloc=True)
+        assert _free_device_bytes() == before
+        _same(again, small)
         _same(big, s.run(300000, seed=3))
         _same(small, s.run(1000, seed=3, first_photon=12345))
         assert big["n_photons"] == 300000 and small["n_photons"] == 1000
