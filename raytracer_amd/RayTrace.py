@@ -33,6 +33,7 @@ class RayTrace:
         self.NumberOfPhotons = 1
         self.Seed = None            # None: fresh entropy per run, like np.random.seed()
         self.Device = None          # None: LOCAL_RANK or 0
+        self.Devices = None         # a list of GPU indices: this process traces on all of them, one host thread each
         self.Precision = _abi.F32
         self.MaxIterations = _scene.REFERENCE_ITERATION_CAP
         self.LastTallies = None
@@ -131,7 +132,9 @@ class RayTrace:
         first, count = distributed.shard_range(int(self.NumberOfPhotons), rank, world)
         sc = self.Scene()
         block = _scene.new_tallies(sc.n_elements)
-        if count > 0:
+        if self.Devices:
+            self._run_on_devices(sc, list(self.Devices), seed, first, count, block)
+        elif count > 0:
             sc.run(count, seed=seed, first_photon=first, device=device,
                    precision=self.Precision, tallies=block)
         distributed.allreduce_tallies(block, device)
@@ -142,6 +145,38 @@ class RayTrace:
         if self.IOOperator.ActivePath and rank == 0:
             self.IOOperator.SaveLog()
         return t
+
+    def _run_on_devices(self, sc, devices, seed, first, count, block):
+        """One process, several GPUs: the photon ids [first, first + count) are cut into one contiguous
+        block per entry of `devices` (the sequential photon loop of reference RayTrace.py:166, sharded),
+        every block is traced by a host thread of its own through rtmc_run on its GPU -- calls on
+        different GPUs run side by side, calls on the same GPU one after the other -- and the integer
+        tallies are added up on the host."""
+        import threading
+        parts = [_scene.new_tallies(sc.n_elements) for _ in devices]
+        errors = []
+
+        def work(k):
+            lo, n = distributed.shard_range(count, k, len(devices))
+            try:
+                if n > 0:
+                    sc.run(n, seed=seed, first_photon=first + lo, device=devices[k],
+                           precision=self.Precision, tallies=parts[k])
+            except Exception as err:        # reported by the calling thread
+                errors.append(err)
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(devices))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        total, arrays = block
+        for part, part_arrays in parts:
+            for key in _abi.TALLY_SCALARS:
+                setattr(total, key, getattr(total, key) + getattr(part, key))
+            for key in arrays:
+                arrays[key] += part_arrays[key]
 
     def CheckElementsForCrossingPoint(self):
         """Nearest valid element on the current trajectory of `self.Photon`

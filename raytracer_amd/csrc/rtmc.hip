@@ -1021,6 +1021,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         }
         return true;
     };
+    size_t run_min = RUN_MIN_MEMBERS;
+    if (const char *e = getenv("RTMC_RUN_MIN")) run_min = std::max(2, atoi(e));  // experiments
     if (sizeof(real) == 4 && !getenv("RTMC_NO_RUNS")) {
         for (size_t fi = 0; fi < frames.size(); fi++)
             for (int k = 0; k < 3; k++) {
@@ -1034,7 +1036,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                     for (const HitRec<real> &o : recs)
                         if (o.p0 == h.p0) members.push_back(o);
                     Run r;
-                    if (members.size() >= RUN_MIN_MEMBERS && rs.size() < 32767 && build_run(members, r)) rs.push_back(r);
+                    if (members.size() >= run_min && rs.size() < 32767 && build_run(members, r)) rs.push_back(r);
                     else planes_done.back() = h.p0, stay.insert(stay.end(), members.begin(), members.end());
                 }
                 // (the records that stay: back into list order)

@@ -138,3 +138,33 @@ def test_bench_launcher_starts_the_ranks_before_touching_a_gpu():
              if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "launch_ranks"]
     first_torch = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Import) and n.names[0].name.startswith("torch"))
     assert order and order[0] < first_torch
+
+
+def test_devices_list_shards_over_host_threads(monkeypatch):
+    """RayTrace.Devices = [...]: the ids are cut into one block per entry, each traced by its own host
+    thread on its own device, and the blocks add up to the tallies of one call (stand-in scene, no GPU)."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dist_worker
+    from raytracer_amd import RayTrace, _abi, configs
+    from raytracer_amd import scene as sc
+    monkeypatch.setattr(sc, "Scene", dist_worker.FakeScene)
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(configs.make_job("C2", 100003))
+    rt.Seed, rt.Device = 3, 0
+    whole = rt.runSimulation()
+    rt.Devices = [0, 1, 2]
+    rt.Scene().calls.clear()
+    split = rt.runSimulation()
+    for k in list(_abi.TALLY_SCALARS) + list(_abi.TALLY_ARRAYS) + ["spectrum"]:
+        assert np.array_equal(np.asarray(whole[k]), np.asarray(split[k])), k
+    calls = sorted(rt.Scene().calls)
+    assert [c[:2] for c in calls] == [(0, 33335), (33335, 33334), (66669, 33334)] and {c[2] for c in calls} == {3}
+
+
+def test_bench_line_describes_the_exchange():
+    """The record of the collective comes from torch.distributed itself; without a process group it says so."""
+    from raytracer_amd import distributed
+    from raytracer_amd import scene as sc
+    info = distributed.collective_info(sc.new_tallies(4))
+    assert info["backend"] is None and info["world_size"] == 1
+    assert info["payload_bytes"] == 8 * (9 + 4 * 4 + 4 * 3800)

@@ -94,3 +94,49 @@ def test_rccl_path_with_one_rank(tmp_path):
         s.close()
     for k in KEYS:
         assert np.array_equal(np.asarray(t[k]), d[k]), k
+
+
+def test_strong_scaling_mode_two_ranks(tmp_path):
+    """`bench.py --total-photons N`: a step is N photon ids cut into one block per rank
+    (`distributed.shard_range`).  Two gloo ranks on GPU 0, an odd N: the line says "strong", names
+    the backend and the number of ranks the process group really had, and the summed tallies are
+    those of one rtmc_run over the same ids."""
+    dump = str(tmp_path / "strong.npz")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--device", "0", "--steps", "2", "--warmup", "1", "--total-photons", "400001",
+                          "--config", "C4", "--no-cpu-baseline", "--dump-tallies", dump],
+                         env=env, stdout=subprocess.PIPE, timeout=300, check=True)
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["world_size"] == 2
+    assert line["collective"]["payload_bytes"] > 8 * 3800
+    assert line["config"]["photons_per_step_total"] == 400001
+    d = np.load(dump)
+    first, n = int(d["first_photon"]), int(d["n_requested"])
+    assert (first, n) == (400001, 2 * 400001) and int(d["n_photons"]) == n
+    s = H.raytrace_for("C4").Scene()
+    try:
+        t = s.run(n, seed=1, first_photon=first)
+    finally:
+        s.close()
+    for k in KEYS:
+        assert np.array_equal(np.asarray(t[k]), d[k]), k
+
+
+def test_one_process_several_devices():
+    """RayTrace.Devices = [0, 0]: two host threads, each tracing half of the ids through rtmc_run
+    (here on the same GPU, where the library runs them one after the other), summed on the host:
+    the tallies of one call over all ids, and the element objects carry them."""
+    rt = H.raytrace_for("C3")
+    rt.NumberOfPhotons, rt.Seed = 250001, 9
+    whole = rt.runSimulation()
+    rt.Devices = [0, 0]
+    split = rt.runSimulation()
+    for k in KEYS:
+        assert np.array_equal(np.asarray(whole[k]), np.asarray(split[k])), k
+    assert rt.OpticalElements[2].Type.Counter == int(whole["counter"][2])
+    rt.Devices = [0, 0, 0]
+    rt.NumberOfPhotons = 2          # fewer photons than threads
+    assert rt.runSimulation()["n_photons"] == 2
