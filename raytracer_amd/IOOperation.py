@@ -26,6 +26,39 @@ MATERIAL_ROW = ["name", "n", "IsAbsorber", "conc_b", "conc_a", "color", "IsAlign
                 "FixDistNeighbors"]
 
 
+_COLUMN_TEXT = {}      # bytes of a column -> its formatted entries (the 3800 bin wavelengths of every detector file)
+
+
+def _formatted_column(col):
+    """'%.18e' of every entry of a float64 column, formatting each distinct bit pattern once."""
+    col = np.ascontiguousarray(col, dtype=np.float64)
+    key = col.tobytes()
+    hit = _COLUMN_TEXT.get(key)
+    if hit is not None:
+        return hit
+    bits, inverse = np.unique(col.view(np.int64), return_inverse=True)
+    texts = np.array(["%.18e" % v for v in bits.view(np.float64).tolist()])[inverse]
+    if len(bits) > 64:        # a column of many distinct values is worth remembering (the bin wavelengths)
+        if len(_COLUMN_TEXT) > 16:
+            _COLUMN_TEXT.clear()
+        _COLUMN_TEXT[key] = texts
+    return texts
+
+
+def write_two_columns(path, table):
+    """The file `np.savetxt(path, table)` writes for an (n, 2) array, byte for byte ('%.18e',
+    one blank, newline), without formatting every number anew: a detector spectrum is 3800 rows of
+    mostly repeated counts, and ten detectors cost the reference's own job sizes more time in
+    `savetxt` than the whole trace takes."""
+    table = np.asarray(table, dtype=np.float64)
+    if table.ndim != 2 or table.shape[1] != 2 or table.shape[0] == 0:
+        np.savetxt(path, table)
+        return
+    lines = np.char.add(np.char.add(_formatted_column(table[:, 0]), " "), _formatted_column(table[:, 1]))
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines.tolist()) + "\n")
+
+
 class LoadSaveRT:
     def __init__(self, Path, RayTracerInstance):
         self.RTI = RayTracerInstance
@@ -114,8 +147,7 @@ class LoadSaveRT:
             typ = oe.Type
             if typ.kind == "Dump":
                 log[i, :3] = [typ.Counter, typ.EnergyCounter, typ.SpectralCounter]
-                np.savetxt(os.path.join(folder, "DetectorSpectrum%d.txt" % i),
-                           typ.IncidentSpectrum)
+                write_two_columns(os.path.join(folder, "DetectorSpectrum%d.txt" % i), typ.IncidentSpectrum)
             else:
                 log[i, 3] = typ.BounceCounter
         np.savetxt(os.path.join(folder, "Logfile.txt"), log)

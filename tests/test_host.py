@@ -314,3 +314,21 @@ def test_random_jobs_survive_the_prt_round_trip(tmp_path):
         assert np.allclose(np.array(back["Elements"], dtype=np.float64), np.array(job["Elements"], dtype=np.float64), rtol=0, atol=0)
         for key in ("ElementProperties", "ElementGeometry", "ElementSize", "Materials", "Photon"):
             assert plain(back[key]) == plain(job[key]), (k, key)
+
+
+def test_fast_spectrum_writer_is_savetxt_byte_for_byte(tmp_path):
+    """DetectorSpectrum<i>.txt (reference IOOperation.py:62, np.savetxt of the 3800 x 2 table):
+    the writer that caches formatted numbers produces the same bytes."""
+    from raytracer_amd import IOOperation
+    rng = np.random.RandomState(2)
+    table = np.stack([np.arange(200.0, 4000.0), rng.poisson(3.0, 3800).astype(np.float64)], axis=1)
+    table[7, 1] = 1.0e15 + 3
+    table[8, 1] = -0.0
+    table[9, 1] = np.nan
+    a, b = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    np.savetxt(a, table)
+    IOOperation.write_two_columns(b, table)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    IOOperation.write_two_columns(b, np.zeros((0, 2)))
+    np.savetxt(a, np.zeros((0, 2)))
+    assert open(a, "rb").read() == open(b, "rb").read()
