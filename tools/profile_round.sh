@@ -4,7 +4,7 @@
 #   bench.py reports as roofline.traffic (stamped with the digest of the kernel sources), and the
 #   cycle stamps of the diagnostic build.  Results under gpurun_out/prof_<round>/; copy into profiles/.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/prof_$R
