@@ -104,6 +104,9 @@ def executed_work(config, per_step, kernel_s, clock_hz=2.37e9):
     return {
         "lane_occupancy": occupancy,
         "valu_issue_frac": issue_cycles / (N_SIMD * clock_hz * kernel_s),
+        # the same with the nominal two cycles of a 64-lane instruction on a 32-lane pipe (157.3 TFLOP/s
+        # = 1024 SIMDs x 32 lanes x 2 flop x 2.4 GHz) and eight for a transcendental
+        "valu_issue_frac_nominal": ((valu - trans) * 2.0 + trans * 8.0) / (N_SIMD * clock_hz * kernel_s),
         "executed_fp32_tflops": wave_flops * 64.0 * occupancy / kernel_s / 1e12,
         "executed_fp32_tflops_all_lanes": wave_flops * 64.0 / kernel_s / 1e12,
         "valu_wave_instructions_per_photon": valu / per_step,

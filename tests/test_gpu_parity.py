@@ -137,7 +137,12 @@ def test_crossing_operation(scenes, oracle_mod, name):
             if el32[k] != el_o[k]:
                 off32 += 1
             elif el_o[k] >= 0:
-                assert d32[k] == pytest.approx(d_o[k], rel=2e-5, abs=2e-6)
+                # SmallestDistance in float32: 1e-6 times the condition of the landing point (helpers.py)
+                L, D = b["loc"][:, k], b["dir"][:, k]
+                n_el = H.element_normal(rt, int(el_o[k]), p_o[k])
+                cos_i = max(abs(float(np.dot(D, n_el))) / float(np.linalg.norm(D)), 1e-300)
+                bound = H.F32_REL * float(H.kappa_landing(L, p_o[k], d_o[k], cos_i))
+                assert abs(d32[k] - d_o[k]) <= bound and np.abs(p32[k] - p_o[k]).max() <= bound, (i, k, d32[k], d_o[k], bound)
     assert total > 300 and off32 <= max(1, total // 500), (off32, total)
     # the host method of the same name on one photon
     ph = rt.Photon
