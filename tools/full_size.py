@@ -1,6 +1,7 @@
 """The BASELINE configurations at their full sizes on one GPU: C3 (co-doped slab, donor->acceptor
-transfer) with 1e10 photons and C5 (sun-spectrum source, per-edge emission spectra) with 1e11,
-each in one call; prints throughput, fates and the edge efficiency beside the reference's runs.
+transfer) and C4 (stacked slabs with reflective edges) with 1e10 photons, C5 (sun-spectrum source,
+per-edge emission spectra) with 1e11, each in one call; prints throughput, fates and the edge
+efficiency beside the reference's runs.
 usage: python tools/full_size.py  (on the GPU box)"""
 import os
 import sys
@@ -13,7 +14,7 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 import helpers as H  # noqa: E402
 
-for name, n in (("C3", 10 ** 10), ("C5", 10 ** 11)):
+for name, n in (("C3", 10 ** 10), ("C4", 10 ** 10), ("C5", 10 ** 11)):
     rt = H.raytrace_for(name)
     s = rt.Scene()
     s.run(10 ** 6, seed=1)
@@ -21,7 +22,7 @@ for name, n in (("C3", 10 ** 10), ("C5", 10 ** 11)):
     t = s.run(n, seed=2)
     wall = time.perf_counter() - t0
     fates = t["n_dumped"] + t["n_internal_converted"] + t["n_capped"] + t["n_lost"]
-    edges = [2, 3, 4, 5]
+    edges = [2, 8, 14] if name == "C4" else [2, 3, 4, 5]      # C4: the one detector edge of each of its three slabs
     eta = float(t["counter"][edges].sum()) / n
     ref = H.ref_tallies(name)
     n_ref = sum(r["n"] for r in ref)
