@@ -377,6 +377,13 @@ int rtmc_op_photon(rtmc_scene *scene, int device, int precision, int op, uint32_
 int rtmc_scene_wavelengths(const rtmc_scene *scene, int64_t *count, double *values,
                            int64_t capacity);
 
+/* What rtmc_scene_create found in the scene (no counterpart in the reference; for tests and for
+ * users who wonder which kernel their scene runs): info[0] = runs of coplanar rectangles in the float32
+ * hit table, info[1] = rectangles in them, info[2] = float32 guard distance: 0 none, 1 on every
+ * search (coplanar overlapping elements), 2 until a photon's first absorption (a strict source aimed at a
+ * seam), info[3] = 1 if the scene runs the kernel that holds every feature. */
+int rtmc_scene_info(const rtmc_scene *scene, int32_t info[4]);
+
 #ifdef __cplusplus
 }
 #endif

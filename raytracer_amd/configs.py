@@ -253,11 +253,11 @@ def tiled_floor_job(n_photons=10000, nx=7, ny=5):
             els.append([[0.5 * (xs[i] + xs[i + 1]), 0.5 * (ys[j] + ys[j + 1]), 0.0], [0.0, 0.0, 1.0]])
             props.append([4, 0, 0, ""])
             sizes.append([0.5 * (xs[i + 1] - xs[i]), 0.5 * (ys[j + 1] - ys[j])])
-    for k in range(0, nx * ny, 3):      # covers tile k and its surroundings
+    for k in range(0, nx * ny, 3):      # covers most of tile k and a little of its neighbours
         c = els[k][0]
         els.append([[c[0] + 0.1, c[1] - 0.1, 0.0], [0.0, 0.0, 1.0]])
         props.append([4, 0, 0, ""])
-        sizes.append([0.6, 0.6])
+        sizes.append([0.3, 0.3])
     hx, hy = 0.5 * (xs[-1] - xs[0]), 0.5 * (ys[-1] - ys[0])
     els.append([[0.0, 0.0, 2.0], [0.0, 0.0, 1.0]]); props.append([1]); sizes.append([hx + 1.0, hy + 1.0])
     for sign in (1.0, -1.0):
@@ -399,6 +399,10 @@ CONFIGS = {
     "C9": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, eqe=EQE_DEMO, scale=2.0,
                           fix_dist=True, fix_dist_r=3.0)),
 }
+
+
+# (bases for rotated_job that are not parity configurations of their own)
+CONFIGS["strips14"] = (strip_job, dict(strips=14))
 
 
 def make_job(name, n_photons=None):

@@ -697,6 +697,7 @@ struct DeviceImage {
     std::vector<HitChunk<real>> hits;
     int n_group[4];
     bool has_runs = false;           // some axis group lists coplanar rectangles as runs (float32 only)
+    int n_runs = 0, n_run_members = 0;
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
     DevSource<real> src;
@@ -944,13 +945,14 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     };
     img.hits.clear();
     img.has_runs = false;
+    img.n_runs = img.n_run_members = 0;
     // float32: RUN_MIN_MEMBERS or more rectangles of a group that lie in one plane (the same p0, bit
     // for bit) leave the group's list and follow it as a run (RunHdr): a grid over their bounding box
     // whose cells name the members that touch them.  A member is entered into every cell its outline,
     // widened by 1e-5 of the box, overlaps: the cell of a landing point is computed in float32 and
     // may come out as a neighbour of the true one.  List order is kept among the records that stay
     // and inside every cell.  A plane whose rectangles crowd more than RUN_CELL_SLOTS into one cell
-    // at every resolution tried stays in the list.
+    // (two words of four one-byte names per cell) at every resolution tried stays in the list.
     struct Run { RunHdr<real> hdr; };
     std::vector<std::vector<Run>> runs(frames.size() * 3);
     std::vector<uint32_t> run_cells;
@@ -981,8 +983,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                 eps[a] = 1e-5 * ext;
             }
             if ((size_t)n[0] * n[1] > 4096) break;
-            std::vector<uint32_t> cells((size_t)n[0] * n[1], 0xFFFFFFFFu);
-            std::vector<int> fill(cells.size(), 0);
+            std::vector<uint32_t> cells(2 * (size_t)n[0] * n[1], 0xFFFFFFFFu);   // two words per cell
+            std::vector<int> fill((size_t)n[0] * n[1], 0);
             bool ok = true;
             for (size_t mi = 0; mi < members.size() && ok; mi++) {
                 const HitRec<real> &m = members[mi];
@@ -996,7 +998,9 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                     for (int ci = first[0]; ci <= last[0] && ok; ci++) {
                         const size_t cell = (size_t)cj * n[0] + ci;
                         if (fill[cell] == RUN_CELL_SLOTS) { ok = false; break; }
-                        cells[cell] = (cells[cell] & ~(0xFFu << (8 * fill[cell]))) | ((uint32_t)mi << (8 * fill[cell]));
+                        uint32_t &word = cells[2 * cell + fill[cell] / 4];
+                        const int shift = 8 * (fill[cell] % 4);
+                        word = (word & ~(0xFFu << shift)) | ((uint32_t)mi << shift);
                         fill[cell]++;
                     }
             }
@@ -1013,7 +1017,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         out.hdr.gi0 = (real)lo[0]; out.hdr.gj0 = (real)lo[1];
         out.hdr.inv_wi = (real)(1.0 / best_w[0]); out.hdr.inv_wj = (real)(1.0 / best_w[1]);
         out.hdr.ni_1 = best_n[0] - 1; out.hdr.nj_1 = best_n[1] - 1;
-        out.hdr.cell_off = (int32_t)run_cells.size();
+        out.hdr.cell_off = (int32_t)(run_cells.size() / 2);
         out.hdr.mem_off = (int32_t)run_members.size();
         run_cells.insert(run_cells.end(), best_cells.begin(), best_cells.end());
         for (const HitRec<real> &m : members) {
@@ -1047,7 +1051,9 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                 if (stay.size() / HIT_CHUNK + 1 > 65535) { rs.clear(); continue; }  // (counts are 16-bit halves)
                 recs.swap(stay);
                 if (!rs.empty()) img.has_runs = true;
+                img.n_runs += (int)rs.size();
             }
+        img.n_run_members = (int)run_members.size();
     }
     auto group_count = [&](size_t fi, int k) {
         return (int)(frames[fi].group[k].size() / HIT_CHUNK) | ((int)runs[fi * 3 + k].size() << 16);
@@ -1594,6 +1600,16 @@ static const void *trace_function(int features)
         default: return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);
         }
     }
+}
+
+RTMC_API int rtmc_scene_info(const rtmc_scene *s, int32_t info[4])
+{
+    if (!s || !info) return fail(RTMC_EINVAL, "null argument");
+    info[0] = s->img32.n_runs;
+    info[1] = s->img32.n_run_members;
+    info[2] = s->has_coplanar ? 1 : (s->seam_source ? 2 : 0);
+    info[3] = trace_function<float>(s->features()) == (const void *)trace_kernel<float, FEAT_ALL> ? 1 : 0;
+    return RTMC_OK;
 }
 
 // Puts the caller's current device back when an entry point returns.

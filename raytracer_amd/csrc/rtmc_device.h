@@ -96,8 +96,8 @@ static_assert(sizeof(FrameHdr<float>) == sizeof(HitChunk<float>) && sizeof(Frame
 // landing point are looked up instead of being tried one after the other.  Such a *run* has a
 // header in the hit table behind the other records of its group (the group's count holds the chunks
 // of those in its low half and the number of runs in its high half) and, in the LDS image, a grid of
-// cells over the members' bounding box in the plane: a cell names the (at most four) members that
-// touch it, in list order.  Float32 tables only.
+// cells over the members' bounding box in the plane: a cell names the (at most eight) members that
+// touch it, in list order, in two words.  Float32 tables only.
 template <typename real>
 struct alignas(64) RunHdr {
     real p0;                  // the plane
@@ -122,7 +122,7 @@ struct alignas(16) RunMember {
     int32_t index;
     int32_t pad[3];
 };
-constexpr int RUN_CELL_SLOTS = 4;       // members a cell can name (one byte each, 0xFF = none)
+constexpr int RUN_CELL_SLOTS = 8;       // members a cell can name (one byte each in two 32-bit words, 0xFF = none)
 
 // One medium.
 template <typename real>
@@ -1212,21 +1212,24 @@ __device__ __forceinline__ void scan_runs_f32(const HitChunk<float> *table, cons
         const int ci = __builtin_amdgcn_fmed3f(__builtin_floorf((Bi - h.gi0) * h.inv_wi), 0.0f, (float)h.ni_1);
         const int cj = __builtin_amdgcn_fmed3f(__builtin_floorf((Bj - h.gj0) * h.inv_wj), 0.0f, (float)h.nj_1);
         // (NaN coordinates -- a line parallel to the plane -- give cell 0 and fail the tests below)
-        uint32_t word = lds.run_cells[h.cell_off + mul24(cj, h.ni_1 + 1) + ci];
+        const uint32_t *cell = lds.run_cells + 2 * (h.cell_off + mul24(cj, h.ni_1 + 1) + ci);
         const bool candidate = (t * adm_q + adm_bias > 0.0f) & (ties_possible ? true : M<float>::abs(t) < M<float>::abs(g.t));
-        word = candidate ? word : 0xFFFFFFFFu;
         Nearest<float> r;
         r.t = ties_possible ? M<float>::inf() : g.t;
         r.e = ties_possible ? -1 : g.e;
-        while (__ballot((word & 0xFFu) != 0xFFu) != 0ull) {
-            const uint32_t slot = word & 0xFFu;
-            word = (word >> 8) | 0xFF000000u;
-            if (slot != 0xFFu) {
-                const RunMember<float> &m = row(lds.run_members, h.mem_off + (int)slot);
-                const bool ok = (M<float>::abs(Bi - m.ci) <= m.hi) & (M<float>::abs(Bj - m.cj) <= m.hj) & (m.index != skip) &
-                                (M<float>::abs(t) < M<float>::abs(r.t));
-                r.t = ok ? t : r.t;
-                r.e = ok ? m.index : r.e;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {   // (the second word is empty in all but crowded cells)
+            uint32_t word = candidate ? cell[half] : 0xFFFFFFFFu;
+            while (__ballot((word & 0xFFu) != 0xFFu) != 0ull) {
+                const uint32_t slot = word & 0xFFu;
+                word = (word >> 8) | 0xFF000000u;
+                if (slot != 0xFFu) {
+                    const RunMember<float> &m = row(lds.run_members, h.mem_off + (int)slot);
+                    const bool ok = (M<float>::abs(Bi - m.ci) <= m.hi) & (M<float>::abs(Bj - m.cj) <= m.hj) & (m.index != skip) &
+                                    (M<float>::abs(t) < M<float>::abs(r.t));
+                    r.t = ok ? t : r.t;
+                    r.e = ok ? m.index : r.e;
+                }
             }
         }
         if (ties_possible) merge_nearest(g, r);

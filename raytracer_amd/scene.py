@@ -363,6 +363,13 @@ class Scene:
             _abi.u64_ptr(tape_off), int(bool(uniform_tape))), self.lib)
         return out
 
+    def info(self):
+        """What the library found in the scene: runs of coplanar rectangles, their members, the float32
+        guard mode (0 none, 1 always, 2 until the first absorption), whether the all-features kernel runs."""
+        out = (C.c_int32 * 4)()
+        _abi.check(self.lib.rtmc_scene_info(self.handle, out), self.lib)
+        return {"runs": out[0], "run_members": out[1], "guard": out[2], "all_features_kernel": bool(out[3])}
+
     def wavelengths(self):
         cnt = C.c_int64()
         _abi.check(self.lib.rtmc_scene_wavelengths(self.handle, C.byref(cnt), None, 0), self.lib)

@@ -264,19 +264,22 @@ def test_strict_sources_aimed_at_a_seam(oracle_mod):
     assert compared["f32"] >= 4 and compared["f64"] >= 4, compared
 
 
-@pytest.mark.parametrize("job", ["strips", "floor", "stack"])
+@pytest.mark.parametrize("job", ["strips", "floor", "stack", "turned strips"])
 def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, job):
     """Six or more rectangles of one plane are looked up through a grid instead of being tried one by
     one (float32 hit table).  The same scenes built with that switched off (RTMC_NO_RUNS) give the same
     integers, photon for photon -- the segmented edge read-out, a floor of 35 unequal tiles partly
     covered by larger detectors of the same plane (list order decides, RayTrace.py:134), a stack of
-    eight slabs whose side faces share four planes -- and float64 agrees with the checker."""
+    eight slabs whose side faces share four planes, the segmented read-out turned rigidly out of the
+    world's axes -- and float64 agrees with the checker."""
     def build():
         rt = RayTrace.RayTrace(demo_scene=False)
         if job == "strips":
             rt.LoadJob(configs.strip_job(10, strips=30))
         elif job == "floor":
             rt.LoadJob(configs.tiled_floor_job(10))
+        elif job == "turned strips":     # no plane axis-aligned: the runs sit in a frame of their own
+            rt.LoadJob(configs.rotated_job(base="strips14", n_photons=10))
         else:
             rt.LoadJob(configs.stacked_job(10, n_slabs=8))
         return rt, rt.Scene()
@@ -285,6 +288,9 @@ def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, jo
     monkeypatch.setenv("RTMC_NO_RUNS", "1")
     _, without = build()
     monkeypatch.delenv("RTMC_NO_RUNS")
+    expected = {"strips": (4, 120), "floor": (1, 47), "stack": (4, 32), "turned strips": (4, 56)}[job]
+    assert (with_runs.info()["runs"], with_runs.info()["run_members"]) == expected
+    assert without.info()["runs"] == 0
     try:
         a, b = with_runs.run(n, seed=31), without.run(n, seed=31)
         for key in ("counter", "spectral", "bounce", "energy_fx", "spectrum"):
