@@ -1,4 +1,4 @@
-# Round-3 measurements in one GPU session (results under gpurun_out/r3m/)
+# Measurements of every configuration in one GPU session (results under gpurun_out/r3m/)
 set -e
 O=gpurun_out/r3m
 mkdir -p $O
