@@ -207,7 +207,7 @@ def rotated_job(base="C2", axis=(0.3, -0.5, 0.8), angle=0.7, n_photons=10000, **
     return job
 
 
-def strip_job(n_photons=10000, strips=14, sun=False):
+def strip_job(n_photons=10000, strips=14, sun=False, enclosed=True):
     """C2 with every edge of the slab cut into `strips` detectors side by side
     (a segmented edge read-out): 4 * strips + 6 detectors, 4 * strips + 8
     elements.  strips = 1 is C2 itself."""
@@ -223,8 +223,9 @@ def strip_job(n_photons=10000, strips=14, sun=False):
             els.append([support, normal])
             props.append([4, 0, 0, ""])
             sizes.append([0.5 * w, 0.5 * thickness])
-    e2, p2, s2 = _dump_box(0.0, 0.0, 0.5 * thickness, 4.0, 2.0)
-    els, props, sizes = els + e2, props + p2, sizes + s2
+    if enclosed:    # (without the box photons that leave the slab find nothing and re-execute their last element)
+        e2, p2, s2 = _dump_box(0.0, 0.0, 0.5 * thickness, 4.0, 2.0)
+        els, props, sizes = els + e2, props + p2, sizes + s2
     photon = _photon(n_photons, (0.0, 2.0, 1.0), STRICT, SUN if sun else FIXED_WL, 460, "air", (0.0, 0.0, -1.0))
     job = {
         "Elements": np.array(els, dtype=np.float64),

@@ -264,7 +264,7 @@ def test_strict_sources_aimed_at_a_seam(oracle_mod):
     assert compared["f32"] >= 4 and compared["f64"] >= 4, compared
 
 
-@pytest.mark.parametrize("job", ["strips", "floor", "stack", "turned strips"])
+@pytest.mark.parametrize("job", ["strips", "floor", "stack", "turned strips", "open strips"])
 def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, job):
     """Six or more rectangles of one plane are looked up through a grid instead of being tried one by
     one (float32 hit table).  The same scenes built with that switched off (RTMC_NO_RUNS) give the same
@@ -278,6 +278,8 @@ def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, jo
             rt.LoadJob(configs.strip_job(10, strips=30))
         elif job == "floor":
             rt.LoadJob(configs.tiled_floor_job(10))
+        elif job == "open strips":       # no box: stale re-executions, after which both directions along the line are admissible
+            rt.LoadJob(configs.strip_job(10, strips=8, enclosed=False))
         elif job == "turned strips":     # no plane axis-aligned: the runs sit in a frame of their own
             rt.LoadJob(configs.rotated_job(base="strips14", n_photons=10))
         else:
@@ -288,7 +290,9 @@ def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, jo
     monkeypatch.setenv("RTMC_NO_RUNS", "1")
     _, without = build()
     monkeypatch.delenv("RTMC_NO_RUNS")
-    expected = {"strips": (4, 120), "floor": (1, 47), "stack": (4, 32), "turned strips": (4, 56)}[job]
+    expected = {"strips": (4, 120), "floor": (1, 47), "stack": (4, 32), "turned strips": (4, 56), "open strips": (4, 32)}[job]
+    if job == "open strips":
+        n = 20000            # (every escaped photon runs to the iteration cap)
     assert (with_runs.info()["runs"], with_runs.info()["run_members"]) == expected
     assert without.info()["runs"] == 0
     try:
@@ -298,14 +302,20 @@ def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, jo
         for key in _abi.TALLY_SCALARS:
             assert a[key] == b[key], key
         assert a["n_photons"] == n and a["n_lost"] == 0
+        if job == "open strips":
+            assert a["n_stale_steps"] > n
         if job == "floor":      # the covering detectors count only beside the tiles
             tiles = int(a["counter"][:35].sum())
             assert tiles > 0.4 * n and 0 < int(a["counter"][35:47].sum()) < 0.1 * n
-        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(100000, seed=32, threads=8)
-        g64 = with_runs.run(100000, seed=32, precision=_abi.F64)
+        m = min(n, 100000)
+        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(m, seed=32, threads=8)
+        g64 = with_runs.run(m, seed=32, precision=_abi.F64)
         moved = int(np.abs(g64["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum())
-        g32 = with_runs.run(100000, seed=32)
+        g32 = with_runs.run(m, seed=32)
         moved32 = int(np.abs(g32["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum())
-        assert moved <= 8 and moved32 <= 40, (moved, moved32)
+        # (the open slab's escaped photons live on stale re-executions, decided by the sign of a rounding
+        # residue: device and host arithmetic part ways for a photon in a hundred there, runs or no runs)
+        limits = (m // 50, m // 50) if job == "open strips" else (8, 40)
+        assert moved <= limits[0] and moved32 <= limits[1], (moved, moved32)
     finally:
         with_runs.close(), without.close()
