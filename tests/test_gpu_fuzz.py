@@ -273,3 +273,53 @@ def test_photon_ids_beyond_32_bits(oracle_mod):
         assert not np.array_equal(low["counter"], high["counter"])
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("seed", range(4 * SCALE))
+def test_random_rectangles_in_one_plane(oracle_mod, monkeypatch, seed):
+    """Six to forty rectangles of random sizes at random places of one wall of a detector box --
+    disjoint, touching, overlapping, nested, in random list positions -- and a hemispherical source
+    facing them: the grid the float32 search looks them up through (runs of coplanar rectangles)
+    gives the integers of the plain list, and float64 follows the checker."""
+    from raytracer_amd import RayTrace, configs
+    rng = np.random.RandomState(9000 + seed)
+    job = configs.tiled_floor_job(10, nx=4, ny=4)      # (its mirror ceiling, four detector walls and floor below: the last six elements)
+    box = [(e, p, s) for e, p, s in zip(job["Elements"].tolist()[-6:], job["ElementProperties"][-6:], job["ElementSize"][-6:])]
+    k = int(rng.randint(6, 41))
+    tiles = []
+    for _ in range(k):
+        h = [float(rng.uniform(0.02, 0.6)), float(rng.uniform(0.02, 0.6))]
+        c = [float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-1.0, 1.0))]
+        if tiles and rng.rand() < 0.3:        # shares an edge with an earlier one
+            pe, _, ps = tiles[int(rng.randint(len(tiles)))]
+            c = [pe[0][0] + ps[0] + h[0], pe[0][1]]
+        tiles.append(([[c[0], c[1], 0.0], [0.0, 0.0, 1.0]], [4, 0, 0, ""], h))
+    everything = tiles + box
+    order = rng.permutation(len(everything))
+    job["Elements"] = np.array([everything[i][0] for i in order], dtype=np.float64)
+    job["ElementProperties"] = [everything[i][1] for i in order]
+    job["ElementSize"] = [everything[i][2] for i in order]
+    job["ElementGeometry"] = [1] * len(everything)
+
+    def build():
+        rt = RayTrace.RayTrace(demo_scene=False)
+        rt.LoadJob(job)
+        return rt, rt.Scene()
+    rt, with_runs = build()
+    monkeypatch.setenv("RTMC_NO_RUNS", "1")
+    _, without = build()
+    monkeypatch.delenv("RTMC_NO_RUNS")
+    try:
+        assert without.info()["runs"] == 0
+        n = 60000
+        a, b = with_runs.run(n, seed=seed), without.run(n, seed=seed)
+        for key in ("counter", "bounce", "spectrum"):
+            assert np.array_equal(a[key], b[key]), (key, with_runs.info())
+        assert a["n_steps"] == b["n_steps"] and a["n_lost"] == 0
+        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=seed, threads=8)
+        g64 = with_runs.run(n, seed=seed, precision=_abi.F64)
+        assert int(np.abs(g64["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()) <= 12
+        assert int(np.abs(a["counter"].astype(np.int64) - cpu["counter"].astype(np.int64)).sum()) <= 60
+        print("seed %d: %d rectangles in the plane, %s" % (seed, k, with_runs.info()))
+    finally:
+        with_runs.close(), without.close()
