@@ -28,7 +28,7 @@ STATUS = ["Start", "Absorbed", "ReemittedDonor", "ReemittedAcceptor", "InternalC
 EXPORTS = ["rtmc_version", "rtmc_last_error", "rtmc_scene_create", "rtmc_scene_destroy",
            "rtmc_run", "rtmc_last_kernel_ms", "rtmc_step_tape", "rtmc_op_intersect",
            "rtmc_scene_wavelengths", "rtmc_op_crossing", "rtmc_run_noalloc", "rtmc_op_photon",
-           "rtmc_scene_info"]
+           "rtmc_scene_info", "rtmc_scene_cells"]
 
 PHOP = {"generate": 1, "absorption": 2, "reflect": 3, "refract": 4, "lens": 5, "polarization": 6,
         "reflectance": 7, "execute": 8, "freepath": 9}          # RTMC_PHOP_*
@@ -144,6 +144,8 @@ def bind(lib):
     lib.rtmc_scene_wavelengths.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _f64p, C.c_int64]
     lib.rtmc_scene_info.restype = C.c_int
     lib.rtmc_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.rtmc_scene_cells.restype = C.c_int
+    lib.rtmc_scene_cells.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     return lib
 
 

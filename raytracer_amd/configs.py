@@ -363,6 +363,68 @@ def escape_cone_job(n_photons=10000, emission=False):
     }
 
 
+def nested_job(n_photons=10):
+    """The slab in its detector box, and a second detector box around that one whose walls are never
+    reached: three cells inside each other."""
+    job = make_job("C2", n_photons)
+    e, p, s = _dump_box(0.0, 0.0, 0.15, 6.0, 3.0)
+    job["Elements"] = np.concatenate([job["Elements"], np.array(e, dtype=np.float64)])
+    job["ElementProperties"] = job["ElementProperties"] + p
+    job["ElementGeometry"] = job["ElementGeometry"] + [1] * 6
+    job["ElementSize"] = job["ElementSize"] + s
+    return job
+
+
+def twin_job(n_photons=10):
+    """Two slabs side by side in one detector box (the box holds two cells: photons between them walk
+    the list), the source above the first."""
+    job = make_job("C2", n_photons)
+    els = job["Elements"].copy()
+    els[:6, 0, 0] -= 1.0                   # first slab: x from -3.5 to 1.5
+    second = job["Elements"][:6].copy()
+    second[:, 0, 0] += 2.8                 # its twin, narrower: x from 1.8 to 3.8
+    sizes = copy.deepcopy(job["ElementSize"][:6])
+    for k in (0, 1, 4, 5):
+        sizes[k][0] = 1.0
+    second[2, 0, 0] = 3.8
+    second[3, 0, 0] = 1.8
+    job["Elements"] = np.concatenate([els, second])
+    job["ElementProperties"] = job["ElementProperties"] + copy.deepcopy(job["ElementProperties"][:6])
+    job["ElementGeometry"] = job["ElementGeometry"] + [1] * 6
+    job["ElementSize"] = job["ElementSize"] + sizes
+    job["Photon"][1] = [-1.0, 0.5, 1.0]
+    job["Photon"][2] = ISOTROPIC
+    return job
+
+
+def near_floor_job(n_photons=10):
+    """The slab 2e-4 cm above the floor of its detector box: the floor comes within the margin of the slab's
+    box, so neither the slab nor the shell around it is a place for a confined search."""
+    job = make_job("C2", n_photons)
+    els = job["Elements"].copy()
+    sizes = copy.deepcopy(job["ElementSize"])
+    floor = -2e-4
+    els[6:10, 0, 2] = 0.5 * (floor + 2.15)   # the box of slab_job spans z = 0.15 -+ 2: shorter walls
+    for k in range(6, 10):
+        sizes[k][1] = 0.5 * (2.15 - floor)
+    els[11, 0, 2] = floor
+    job["Elements"] = els
+    job["ElementSize"] = sizes
+    return job
+
+
+def mirror_box_job(n_photons=10):
+    """The slab in a box of five mirrors and a detector floor: what leaves the slab upwards or sideways
+    comes back from the walls (a photon that has met a wall no longer "moves away from the slab" and
+    walks the list), everything ends on the floor or in the slab."""
+    job = make_job("C2", n_photons)
+    props = copy.deepcopy(job["ElementProperties"])
+    for k in range(6, 11):
+        props[k] = [1]
+    job["ElementProperties"] = props
+    return job
+
+
 def synthetic_am15():
     """Two-column stand-in for the sun table the reference expects in
     `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with

@@ -76,6 +76,7 @@ __device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char 
     l.bin = reinterpret_cast<const uint16_t *>(smem + sc.lay.bin);
     l.run_cells = reinterpret_cast<const uint32_t *>(smem + sc.lay.run_cells);
     l.run_members = reinterpret_cast<const RunMember<real> *>(smem + sc.lay.run_members);
+    l.cells = reinterpret_cast<const CellHeader *>(smem + sc.lay.cells);
     l.acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
     l.hist = reinterpret_cast<uint32_t *>(smem + sc.lay.hist);
     return l;
@@ -96,7 +97,8 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask)
 // NEED_EMIT: absorbed, still at the point where its last search began.  Both are
 // dealt with at the head of the renew block, for the lanes of all iterations
 // since the last pass at once.
-enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3, NEED_RETIRE = 4 };
+// NEED_WIDE (kernels with FEAT_CELLS): the photon's next search has to walk the element list.
+enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3, NEED_RETIRE = 4, NEED_WIDE = 5 };
 // When to run the renew block.  It costs R (about half a loop iteration)
 // whatever the number of lanes in it, while every lane that waits for it wastes
 // 1/64 of an iteration S per iteration.  Running it every P iterations costs
@@ -112,6 +114,15 @@ enum { NEED_NONE = 0, NEED_LAUNCH = 1, NEED_EMIT = 2, NEED_OFF = 3, NEED_RETIRE 
 #define RTMC_RENEW_DEBT 32
 #endif
 constexpr int RENEW_DEBT = RTMC_RENEW_DEBT;  // lane-iterations
+// Kernels with FEAT_CELLS: a pass of the loop searches either per lane from the photons' cells (cheap; lanes
+// whose photon is not confined to a cell sit it out) or by walking the element list for every lane.  The same
+// reasoning as for the renew block: the list walk costs its extra cycles whatever the number of lanes that
+// need it, every lane that waits for it wastes 1/64 of a pass, so it runs once the lane-passes spent waiting
+// reach a threshold (or when no lane can do without it).
+#ifndef RTMC_WIDE_DEBT
+#define RTMC_WIDE_DEBT 16
+#endif
+constexpr int WIDE_DEBT = RTMC_WIDE_DEBT;  // lane-passes
 
 // Register budget: the float32 kernels are compiled for six waves per SIMD
 // (three 512-thread workgroups per CU, at most 80 VGPRs; the lean instantiation
@@ -136,6 +147,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
              unsigned long long *work)
 {
     constexpr bool ALIGNED = (FEATURES & FEAT_ALIGNED) != 0;
+    constexpr bool CELLS = (FEATURES & FEAT_CELLS) != 0 && sizeof(real) == 4;
     extern __shared__ __align__(16) unsigned char smem[];
     SceneArg<real> sc = scene_ref(scene);
     Lds<real> lds = stage_lds(sc, smem, true);
@@ -162,10 +174,11 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     uint64_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;
     int idle_debt = 0;  // wave-uniform: lane-iterations spent waiting for the renew block
+    [[maybe_unused]] int wide_debt = 0;  // wave-uniform: lane-passes spent waiting for a walk over the element list
     const uint32_t lane = threadIdx.x & 63;
 
 #ifdef RTMC_PROFILE_SECTIONS
-    unsigned long long cyc_renew = 0, cyc_step = 0, n_renew = 0, n_step = 0, lanes_renew = 0, lanes_step = 0;
+    unsigned long long cyc_renew = 0, cyc_step = 0, n_renew = 0, n_step = 0, lanes_renew = 0, lanes_step = 0, n_walk = 0;
 #define SECTION_BEGIN() const unsigned long long sec_t0 = __builtin_readcyclecounter()
 #define SECTION_END(acc, cnt, lanes, mask) do { acc += __builtin_readcyclecounter() - sec_t0; cnt++; lanes += __popcll(mask); } while (0)
 #else
@@ -176,7 +189,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
         // (Single exit and no `continue`: with two back edges the compiler copied the
         // whole photon record to other registers and back on every iteration.)
         const unsigned long long want = __ballot(need == NEED_LAUNCH || need == NEED_EMIT || need == NEED_RETIRE);
-        const unsigned long long stepping = __ballot(need == NEED_NONE);
+        const unsigned long long stepping = __ballot(need == NEED_NONE || (CELLS && need == NEED_WIDE));
         if ((want | stepping) == 0ull) break;  // every lane is switched off
         idle_debt += __popcll(want);
         if (want != 0ull && (idle_debt >= RENEW_DEBT || stepping == 0ull)) {
@@ -258,7 +271,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                 if (special)
                     renew_emit_aligned(hot, lds, row(lds.mats, p.mat), p, g, emit_iter);
                 else
-                    renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0, (FEATURES & FEAT_SPECTRA) != 0>(sc, hot, lds, p, g, launching);
+                    renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0, (FEATURES & FEAT_SPECTRA) != 0, CELLS>(sc, hot, lds, p, g, launching);
                 need = NEED_NONE;
                 tally.stamp(8);
             }
@@ -266,9 +279,21 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
         }
         SECTION_BEGIN();
 #ifdef RTMC_PROFILE_SECTIONS
-        const unsigned long long step_mask = __ballot(need == NEED_NONE);
+        const unsigned long long step_mask = __ballot(need == NEED_NONE || (CELLS && need == NEED_WIDE));
 #endif
-        if (need == NEED_NONE) {
+        if constexpr (CELLS) {
+            const unsigned long long waiting = __ballot(need == NEED_WIDE);
+            wide_debt += __popcll(waiting);
+            const bool walk_list = waiting != 0ull && (wide_debt >= WIDE_DEBT || __ballot(need == NEED_NONE) == 0ull);
+            if (walk_list) wide_debt = 0;
+            if (need == NEED_NONE || (walk_list && need == NEED_WIDE)) {
+                const StepResult r = photon_step<FEATURES, true>(hot, lds, p, g, tally, walk_list);
+                need = r == STEP_ENDED ? NEED_RETIRE : (r == STEP_ABSORBED ? NEED_EMIT : (r == STEP_WIDE ? NEED_WIDE : NEED_NONE));
+            }
+#ifdef RTMC_PROFILE_SECTIONS
+            if (lane == 0) { n_walk += walk_list ? 1 : 0; }
+#endif
+        } else if (need == NEED_NONE) {
             const StepResult r = photon_step<FEATURES, true>(hot, lds, p, g, tally);
             need = r == STEP_ENDED ? NEED_RETIRE : (r == STEP_ABSORBED ? NEED_EMIT : NEED_NONE);
         }
@@ -278,6 +303,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     if (lane == 0) {  // per-wave totals behind the work counter
         atomicAdd(&work[8], cyc_renew); atomicAdd(&work[9], n_renew); atomicAdd(&work[10], lanes_renew);
         atomicAdd(&work[11], cyc_step); atomicAdd(&work[12], n_step); atomicAdd(&work[13], lanes_step);
+        atomicAdd(&work[14], n_walk);
         atomicAdd(&work[44], __builtin_amdgcn_s_memtime() - life_c0);
         atomicAdd(&work[45], __builtin_amdgcn_s_memrealtime() - life_r0);
     }
@@ -305,6 +331,32 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
     for (int i = threadIdx.x; i < n_hist; i += blockDim.x) {
         uint32_t v = lds.hist[i];
         if (v) atomicAdd(&tl.hist[i], (unsigned long long)v);
+    }
+}
+
+// The first search of a strict source's photons has the same answer for every one of them.  The
+// kernels with cells take it from the header of the cell table instead of walking the element
+// list; this kernel, run once when a scene is uploaded, finds it with that very walk (one wave, all
+// lanes alike) and marks the launch flags if there is a hit.
+__global__ void __launch_bounds__(64)
+preset_hit_kernel(const DevScene<float> *scene, CellHeader *hdr)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    SceneArg<float> sc = scene_ref(scene);
+    Lds<float> lds = stage_lds(sc, smem, false);
+    const HotScene<float> hot = hot_scene(sc);
+    Photon<float> p;
+    p.Lx = sc.src.loc[0]; p.Ly = sc.src.loc[1]; p.Lz = sc.src.loc[2];
+    p.Dx = sc.src.dir[0]; p.Dy = sc.src.dir[1]; p.Dz = sc.src.dir[2];
+    p.Ex = p.Ey = p.Ez = 0.0f;
+    p.wid = sc.src.wid_fixed;
+    init_photon_common(sc, p);
+    float dnorm;
+    const Nearest<float> first = nearest_valid_hit<0>(hot, lds, p, dnorm);
+    if (threadIdx.x == 0 && first.e >= 0) {
+        hdr->preset_t = first.t;
+        hdr->preset_e = first.e;
+        hdr->launch_flags |= F_PRESET;
     }
 }
 
@@ -704,6 +756,15 @@ struct DeviceImage {
     bool back_possible = false;  // some medium's thresholds let the acceptor hand the excitation back
 };
 
+// Closed boxes among the rectangles of a scene (see DevCell), found once per scene from its description.
+struct CellPlan {
+    std::vector<DevCell> cells;          // two records per cell (see DevCell); cell 0 = "no cell"
+    std::vector<uint8_t> el_cell;        // per element: the cell it is a face of (0 none)
+    std::vector<uint8_t> el_outer;       //              and the cell around that one (0 none)
+    int start_cell = 0;                  // innermost cell that holds the source
+    int n_usable = 0;                    // cells in which some photon can be confined (leaf or simple)
+};
+
 struct PerDevice {
     bool ready = false;
     hipStream_t stream = nullptr;
@@ -780,13 +841,17 @@ struct rtmc_scene {
     bool seam_source = false;       // a strict source is aimed at a seam: guard distance until a photon's first absorption
     bool hist_in_hbm = false;       // detectors x bins too large for the LDS in some precision
     bool has_runs = false;          // the float32 hit table lists coplanar rectangles as runs
+    bool has_cells = false;         // some rectangles close boxes in which photons can be confined (float32)
+    int n_cells = 0, n_cells_usable = 0, start_cell = 0;
     int features() const
     {
         if (has_area || has_coplanar || seam_source || hist_in_hbm) return FEAT_ALL;
         return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES | FEAT_FRAMES : 0) |
                (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0) |
-               (has_runs ? FEAT_RUNS : 0);
+               (has_runs ? FEAT_RUNS : 0) | (cells_in_use() ? FEAT_CELLS : 0);
     }
+    // the kernels with cells exist for rectangle-only scenes of the world frame without runs
+    bool cells_in_use() const { return has_cells && !has_shapes && !has_frames && !has_runs; }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
@@ -804,6 +869,187 @@ struct rtmc_scene {
 
 namespace {
 
+// Finds the cells of a scene: sets of six rectangles of the world frame (normal and in-plane axes
+// exactly along the coordinate axes) that close a box, each face spanning exactly the box.  A cell
+// is usable for the confined search if nothing but its faces comes near its box (CELL_LEAF), or if
+// everything that does belongs to one cell nested in it (CELL_SIMPLE).  Lenses are no faces (a
+// photon passes them without the refraction that moves it from cell to cell).
+CellPlan find_cells(const rtmc_scene_desc *d)
+{
+    CellPlan plan;
+    const int n_el = d->n_elements;
+    plan.el_cell.assign(n_el, 0);
+    plan.el_outer.assign(n_el, 0);
+    DevCell none;
+    memset(&none, 0, sizeof none);
+    for (int k = 0; k < 3; k++) none.hw[k] = -1.0f;   // no photon is in it
+    plan.cells.assign(2, none);
+    if (getenv("RTMC_NO_CELLS")) return plan;
+
+    struct Face { int el, axis; double p, c[3], h[3]; };
+    auto unit_axis = [](const double *v) {   // index of the coordinate axis v is (plus or minus), exactly; else -1
+        int k = -1;
+        for (int a = 0; a < 3; a++) {
+            if (v[a] == 0.0) continue;
+            if (std::fabs(v[a]) != 1.0 || k >= 0) return -1;
+            k = a;
+        }
+        return k;
+    };
+    std::vector<Face> faces[3];
+    double scale = 1.0;
+    for (int i = 0; i < n_el; i++) {
+        const rtmc_element &e = d->elements[i];
+        for (int a = 0; a < 3; a++) scale = std::max(scale, std::fabs(e.support[a]));
+        if (e.geometry != RTMC_GEOM_RECTANGLE || e.type == RTMC_TYPE_LENS) continue;
+        const int kn = unit_axis(e.normal), k1 = unit_axis(e.e1), k2 = unit_axis(e.e2);
+        if (kn < 0 || k1 < 0 || k2 < 0 || kn == k1 || kn == k2 || k1 == k2) continue;
+        if (!(e.half1 > 0) || !(e.half2 > 0)) continue;
+        Face f;
+        f.el = i; f.axis = kn; f.p = e.support[kn];
+        for (int a = 0; a < 3; a++) { f.c[a] = e.support[a]; f.h[a] = 0; }
+        f.h[k1] = e.half1; f.h[k2] = e.half2;
+        faces[kn].push_back(f);
+    }
+    const double tol = 1e-9 * scale;
+    struct Box { double lo[3], hi[3]; int face[3][2]; bool dropped = false; int parent = -1; };
+    std::vector<Box> boxes;
+    auto near = [&](double a, double b) { return std::fabs(a - b) <= tol; };
+    // the face of `axis` at plane `p` that spans exactly lo..hi along the other two axes; -2 if there are several
+    auto find_face = [&](int axis, double p, const double *lo, const double *hi) {
+        int found = -1;
+        for (const Face &f : faces[axis]) {
+            if (!near(f.p, p)) continue;
+            bool spans = true;
+            for (int a = 0; a < 3; a++)
+                if (a != axis) spans = spans && near(f.c[a] - f.h[a], lo[a]) && near(f.c[a] + f.h[a], hi[a]);
+            if (!spans) continue;
+            if (found >= 0) return -2;
+            found = f.el;
+        }
+        return found;
+    };
+    for (const Face &A : faces[0]) {
+        // the nearest face above A with the same outline closes the box along x
+        const Face *B = nullptr;
+        for (const Face &o : faces[0])
+            if (o.p > A.p + tol && near(o.c[1], A.c[1]) && near(o.c[2], A.c[2]) && near(o.h[1], A.h[1]) && near(o.h[2], A.h[2]) &&
+                (!B || o.p < B->p)) B = &o;
+        if (!B) continue;
+        Box b;
+        b.lo[0] = A.p; b.hi[0] = B->p;
+        for (int a = 1; a < 3; a++) { b.lo[a] = A.c[a] - A.h[a]; b.hi[a] = A.c[a] + A.h[a]; }
+        bool closed = true;
+        for (int a = 0; a < 3 && closed; a++) {
+            b.face[a][0] = find_face(a, b.lo[a], b.lo, b.hi);
+            b.face[a][1] = find_face(a, b.hi[a], b.lo, b.hi);
+            closed = b.face[a][0] >= 0 && b.face[a][1] >= 0;
+        }
+        if (closed && boxes.size() < 254) boxes.push_back(b);
+    }
+    // a rectangle that is a face of two boxes (two boxes sharing a wall) would have to move a photon between
+    // three cells: neither box becomes a cell
+    {
+        std::vector<int> uses(n_el, 0);
+        for (const Box &b : boxes)
+            for (int a = 0; a < 3; a++) { uses[b.face[a][0]]++; uses[b.face[a][1]]++; }
+        for (Box &b : boxes)
+            for (int a = 0; a < 3; a++)
+                if (uses[b.face[a][0]] > 1 || uses[b.face[a][1]] > 1) b.dropped = true;
+        boxes.erase(std::remove_if(boxes.begin(), boxes.end(), [](const Box &b) { return b.dropped; }), boxes.end());
+    }
+    if (boxes.empty()) return plan;
+    auto extent = [](const Box &b) { return std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2])); };
+    // b strictly inside a, by a's margin
+    auto inside = [&](const Box &b, const Box &a) {
+        const double m = 1e-4 * extent(a);
+        for (int k = 0; k < 3; k++)
+            if (!(a.lo[k] + m <= b.lo[k] && b.hi[k] + m <= a.hi[k])) return false;
+        return true;
+    };
+    auto volume = [](const Box &b) { return (b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); };
+    const int n_box = (int)boxes.size();
+    for (int i = 0; i < n_box; i++)
+        for (int j = 0; j < n_box; j++)
+            if (i != j && inside(boxes[i], boxes[j]) && (boxes[i].parent < 0 || volume(boxes[j]) < volume(boxes[boxes[i].parent])))
+                boxes[i].parent = j;
+    std::vector<int> face_of(n_el, -1);
+    for (int i = 0; i < n_box; i++)
+        for (int a = 0; a < 3; a++) { face_of[boxes[i].face[a][0]] = i; face_of[boxes[i].face[a][1]] = i; }
+    // bounding box of any element
+    auto bounds = [&](const rtmc_element &e, double *lo, double *hi) {
+        for (int a = 0; a < 3; a++) {
+            double r;
+            if (e.geometry == RTMC_GEOM_RECTANGLE) r = std::fabs(e.e1[a]) * e.half1 + std::fabs(e.e2[a]) * e.half2;
+            else if (e.geometry == RTMC_GEOM_CIRCLE) r = e.half1;
+            else if (e.geometry == RTMC_GEOM_TRIANGLE) {
+                lo[a] = std::min(e.e1[a], std::min(e.e2[a], e.vertex3[a]));
+                hi[a] = std::max(e.e1[a], std::max(e.e2[a], e.vertex3[a]));
+                continue;
+            } else {  // cylinder: support and normal are the end points of the axis
+                lo[a] = std::min(e.support[a], e.normal[a]) - e.half1;
+                hi[a] = std::max(e.support[a], e.normal[a]) + e.half1;
+                continue;
+            }
+            lo[a] = e.support[a] - r; hi[a] = e.support[a] + r;
+        }
+    };
+    plan.cells.resize(2 * (1 + n_box), none);
+    for (int i = 0; i < n_box; i++) {
+        const Box &b = boxes[i];
+        const double m = 1e-4 * extent(b);
+        bool dirty = false;
+        int children = 0;
+        for (int j = 0; j < n_box; j++)
+            if (boxes[j].parent == i) children++;
+        for (int e = 0; e < n_el && !dirty; e++) {
+            if (face_of[e] == i) continue;
+            double lo[3], hi[3];
+            bounds(d->elements[e], lo, hi);
+            bool apart = false;
+            for (int k = 0; k < 3; k++) apart = apart || hi[k] < b.lo[k] - m || lo[k] > b.hi[k] + m;
+            if (apart) continue;
+            // it comes near this box: fine only as (part of) a cell nested in this one
+            int owner = face_of[e];
+            while (owner >= 0 && boxes[owner].parent != i) owner = boxes[owner].parent;
+            if (owner < 0) dirty = true;
+        }
+        bool fits = true;
+        DevCell c;
+        memset(&c, 0, sizeof c);
+        for (int k = 0; k < 3; k++) {
+            c.plo[k] = (float)d->elements[b.face[k][0]].support[k];
+            c.phi[k] = (float)d->elements[b.face[k][1]].support[k];
+            c.idlo[k] = b.face[k][0]; c.idhi[k] = b.face[k][1];
+            c.c[k] = (float)(0.5 * (b.lo[k] + b.hi[k]));
+            c.hw[k] = (float)(0.5 * (b.hi[k] - b.lo[k]) + 1e-5 * extent(b));
+            if (!(c.plo[k] < c.phi[k])) fits = false;   // (a box float32 cannot resolve)
+        }
+        DevCell unusable = c;
+        for (int k = 0; k < 3; k++) unusable.hw[k] = -1.0f;
+        const bool leaf = fits && !dirty && children == 0, simple = fits && !dirty && children == 1;
+        plan.cells[2 * (1 + i)] = leaf ? c : unusable;
+        plan.cells[2 * (1 + i) + 1] = (leaf || simple) ? c : unusable;
+        if (leaf || simple) plan.n_usable++;
+        for (int k = 0; k < 3; k++)
+            for (int side = 0; side < 2; side++) {
+                plan.el_cell[b.face[k][side]] = (uint8_t)(1 + i);
+                plan.el_outer[b.face[k][side]] = (uint8_t)(b.parent < 0 ? 0 : 1 + b.parent);
+            }
+    }
+    // the innermost box that holds the source, clear of its faces
+    int start = -1;
+    for (int i = 0; i < n_box; i++) {
+        const Box &b = boxes[i];
+        const double m = 1e-4 * extent(b);
+        bool in = true;
+        for (int k = 0; k < 3; k++) in = in && b.lo[k] + m < d->source.location[k] && d->source.location[k] < b.hi[k] - m;
+        if (in && (start < 0 || volume(b) < volume(boxes[start]))) start = i;
+    }
+    plan.start_cell = start < 0 ? 0 : 1 + start;
+    return plan;
+}
+
 template <typename real>
 void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<std::vector<double>> &cdfs, const std::vector<int> &cdf_off,
@@ -811,7 +1057,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<int> &cdf_wid_off, const std::vector<int> &mat_abs_slot,
                  const std::vector<HostTable> &absA, const std::vector<HostTable> &absD, int src_cdf,
                  const std::vector<uint32_t> &energy_fx, const std::vector<uint16_t> &wid_cbin, int n_bins,
-                 const std::vector<int32_t> &el_slot, int n_dump, DeviceImage<real> &img)
+                 const std::vector<int32_t> &el_slot, int n_dump, const CellPlan &plan, DeviceImage<real> &img)
 {
     const int n_el = d->n_elements, n_mat = d->n_materials;
     const int n_wid = (int)wl.size();
@@ -854,7 +1100,11 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         }
         o.type = e.type | (e.geometry << 8);
         o.info = 0;
-        if (e.type == RTMC_TYPE_INTERFACE) o.info = e.material1 | (e.material2 << 8);
+        // (interfaces and mirrors: the cell the element is a face of and the cell around that one in the upper
+        // half, read by the kernels with FEAT_CELLS only)
+        if (e.type == RTMC_TYPE_INTERFACE || e.type == RTMC_TYPE_MIRROR)
+            o.info = ((int32_t)plan.el_cell[i] << 16) | (int32_t)((uint32_t)plan.el_outer[i] << 24);
+        if (e.type == RTMC_TYPE_INTERFACE) o.info |= e.material1 | (e.material2 << 8);
         if (e.type == RTMC_TYPE_DUMP) o.info = ((e.eqe_table + 1) & 0xFF) | (el_slot[i] << 8);
     }
     // interface records carry what the operation needs to know about both media
@@ -1189,6 +1439,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.bin = (uint32_t)off; off = align(off + 2 * wid_cbin.size());
     lay.run_cells = (uint32_t)off; off = align(off + 4 * run_cells.size());
     lay.run_members = (uint32_t)off; off = align(off + sizeof(RunMember<real>) * run_members.size());
+    lay.cells = (uint32_t)off; off = align(off + sizeof(CellHeader) + sizeof(DevCell) * plan.cells.size());
     lay.acc = (uint32_t)off;
     lay.n_wid = (uint32_t)n_wid;
     lay.n_bins = (uint32_t)n_bins;
@@ -1213,6 +1464,15 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     memcpy(img.lds.data() + lay.bin, wid_cbin.data(), 2 * wid_cbin.size());
     if (!run_cells.empty()) memcpy(img.lds.data() + lay.run_cells, run_cells.data(), 4 * run_cells.size());
     if (!run_members.empty()) memcpy(img.lds.data() + lay.run_members, run_members.data(), sizeof(RunMember<real>) * run_members.size());
+    {
+        CellHeader hdr;
+        memset(&hdr, 0, sizeof hdr);
+        hdr.preset_e = -1;
+        hdr.launch_flags = (uint32_t)plan.start_cell << F_CELL_SHIFT;   // (F_PRESET: set on the device, see preset_hit_kernel)
+        hdr.n_cells = (int32_t)plan.cells.size() / 2 - 1;
+        memcpy(img.lds.data() + lay.cells, &hdr, sizeof hdr);
+        memcpy(img.lds.data() + lay.cells + sizeof hdr, plan.cells.data(), sizeof(DevCell) * plan.cells.size());
+    }
 
     const rtmc_source &s = d->source;
     DevSource<real> &o = img.src;
@@ -1513,8 +1773,11 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
         for (size_t w = 0; w < wl.size(); w++)
             s->eqeT[(size_t)t * wl.size() + w] = threshold32(q.y[nearest_index(q.x, wl[w])]);
     }
-    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img32);
-    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, s->img64);
+    const CellPlan plan = find_cells(d);
+    s->has_cells = plan.n_usable > 0;
+    s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
+    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, plan, s->img32);
+    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, plan, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
     s->has_frames = (s->img32.n_group[3] >> 16) != 0;
     s->has_runs = s->img32.has_runs;
@@ -1593,6 +1856,18 @@ static const void *trace_function(int features)
             default: return (const void *)trace_kernel<real, FEAT_RUNS | FEAT_SPECTRA | FEAT_BACK>;
             }
         }
+        if (features & FEAT_CELLS) {  // cells: rectangle-only scenes of the world frame (rtmc_scene::cells_in_use)
+            const bool aligned = (features & FEAT_ALIGNED) != 0;
+            switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+            case 0: return aligned ? (const void *)trace_kernel<real, FEAT_CELLS | FEAT_ALIGNED> : (const void *)trace_kernel<real, FEAT_CELLS>;
+            case FEAT_SPECTRA: return aligned ? (const void *)trace_kernel<real, FEAT_CELLS | FEAT_SPECTRA | FEAT_ALIGNED>
+                                              : (const void *)trace_kernel<real, FEAT_CELLS | FEAT_SPECTRA>;
+            case FEAT_BACK: return aligned ? (const void *)trace_kernel<real, FEAT_CELLS | FEAT_BACK | FEAT_ALIGNED>
+                                           : (const void *)trace_kernel<real, FEAT_CELLS | FEAT_BACK>;
+            default: return aligned ? (const void *)trace_kernel<real, FEAT_CELLS | FEAT_SPECTRA | FEAT_BACK | FEAT_ALIGNED>
+                                    : (const void *)trace_kernel<real, FEAT_CELLS | FEAT_SPECTRA | FEAT_BACK>;
+            }
+        }
         switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
         case 0: return trace_variant<real, 0>(features);
         case FEAT_SPECTRA: return trace_variant<real, FEAT_SPECTRA>(features);
@@ -1600,6 +1875,16 @@ static const void *trace_function(int features)
         default: return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);
         }
     }
+}
+
+RTMC_API int rtmc_scene_cells(const rtmc_scene *s, int32_t info[4])
+{
+    if (!s || !info) return fail(RTMC_EINVAL, "null argument");
+    info[0] = s->n_cells;
+    info[1] = s->n_cells_usable;
+    info[2] = s->start_cell;
+    info[3] = (s->features() & FEAT_CELLS) ? 1 : 0;
+    return RTMC_OK;
 }
 
 RTMC_API int rtmc_scene_info(const rtmc_scene *s, int32_t info[4])
@@ -1689,7 +1974,8 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     // scene must not lower the limit under an earlier, larger one).
     const int lds_limit = 160 * 1024;
     for (const void *fn : {trace32, trace64, (const void *)step_tape_kernel<float>, (const void *)photon_op_kernel<float>,
-                           (const void *)step_tape_kernel<double>, (const void *)photon_op_kernel<double>})
+                           (const void *)step_tape_kernel<double>, (const void *)photon_op_kernel<double>,
+                           (const void *)preset_hit_kernel})
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
     {  // the workgroup size that puts the most waves on a SIMD; the smaller one on a tie
         int best_waves = -1;
@@ -1716,6 +2002,14 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     {
         int rc = upload_scene_structs(s, p);
         if (rc) return rc;
+    }
+    // kernels with cells, strict point source: the first hit of every photon, found once by the search itself
+    if ((s->features() & FEAT_CELLS) && s->img32.src.dir_mode == 0 && !s->has_area && !getenv("RTMC_NO_PRESET")) {
+        CellHeader *hdr = (CellHeader *)((char *)p.lds32 + s->img32.lay.cells);
+        hipLaunchKernelGGL(preset_hit_kernel, dim3(1), dim3(64), s->img32.lay.total, p.stream,
+                           (const DevScene<float> *)p.scene32, hdr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(p.stream));
     }
     p.ready = true;
     return RTMC_OK;
@@ -1844,7 +2138,7 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
     *kernel_ms += ms;
 #ifdef RTMC_PROFILE_SECTIONS
     {
-        unsigned long long w[48];
+        unsigned long long w[64];
         HIP_TRY(hipMemcpy(w, dev_work, sizeof w, hipMemcpyDeviceToHost));
         const double total = (double)(w[8] + w[11]);
         fprintf(stderr, "[rtmc] sections: renew %llu passes, %.0f cycles each, %.1f lanes; step %llu passes, %.0f cycles each, %.1f lanes; "
@@ -1856,6 +2150,8 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
                  (double)w[11] * (double)w[13] / (double)std::max(1ull, w[12])) / (64.0 * total));
         fprintf(stderr, "[rtmc]   shader clock while the waves ran: %.0f MHz (cycle counter against the 100 MHz counter, all waves)\n",
                 100.0 * (double)w[44] / (double)std::max(1ull, w[45]));
+        if (s->features() & FEAT_CELLS)
+            fprintf(stderr, "[rtmc]   step passes that walked the element list: %llu of %llu\n", w[14], w[12]);
         static const char *names[9] = {"step: philox", "step: search", "step: absorption check", "step: element operation",
                                        "renew: endings", "renew: pathway + wavelength", "renew: photon ids",
                                        "renew: philox", "renew: direction, polarisation, free path"};

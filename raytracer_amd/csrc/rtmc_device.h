@@ -44,7 +44,8 @@ template <typename real>
 struct DevElem {
     real nx, ny, nz, d0;
     int32_t type;   // RTMC_TYPE_* | RTMC_GEOM_* << 8
-    int32_t info;   // interface: material1 | material2 << 8; dump: (eqe table + 1) | detector slot << 8
+    int32_t info;   // interface: material1 | material2 << 8; dump: (eqe table + 1) | detector slot << 8;
+                    // interface and mirror: cell the element is a face of << 16 | cell around that one << 24 (DevCell)
     int32_t nid1;   // interface: name id of material1 (Elements.py:45 compares names)
     int32_t slots;  // interface: (absorption slot of material1 + 1) | (slot of material2 + 1) << 16
     real n1v, n2v;  // interface: refractive indices of material1 / material2
@@ -124,6 +125,35 @@ struct alignas(16) RunMember {
 };
 constexpr int RUN_CELL_SLOTS = 8;       // members a cell can name (one byte each in two 32-bit words, 0xFF = none)
 
+// A *cell*: six rectangles of the world frame that close an axis-aligned box.  A photon that is
+// inside such a box, with nothing else in it, can only meet one of the three faces its direction
+// points at, so its search needs no walk over the element list: see confined_hit.  Cells may be
+// nested (a slab inside a detector box); a photon carries the number of the innermost cell it is
+// in (Photon::flags) and changes it when it is refracted through a face.  Float32 tables only.
+// Record 0 of the table stands for "no cell" and fails every test.
+struct alignas(16) DevCell {
+    float plo[3], phi[3];  // plane coordinate (HitRec::p0) of the faces normal to x | y | z, low and high side
+    float c[3];            // centre of the box
+    float hw[3];           // half extents plus a margin: farther out a point is not taken to be in the cell
+                           // (negative: the record is not usable, every search from it fails)
+    int32_t idlo[3], idhi[3];  // element indices of the low and high faces
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevCell) == 80, "five 16-byte LDS reads per lane");
+// Every cell has two records: [2 cell] for a photon that is simply in it, [2 cell + 1] for one whose last operation
+// was on a face of a cell nested in it, from which it now moves away (F_OUTBOUND: refracted out of the nested cell
+// or reflected off it from outside).  A record is usable if
+//   [2 cell]      nothing but the cell's faces touches its box: every photon in it is confined;
+//   [2 cell + 1]  the same, or the box holds exactly one other cell and nothing else: the photon that moves away
+//                 from that cell cannot meet it again (it is convex) and is confined to the shell around it.
+// In front of the cell records: what a launched photon starts with.
+struct alignas(16) CellHeader {
+    float preset_t;          // strict source: line parameter and element of the first hit of every photon,
+    int32_t preset_e;        //   found once per scene by the search itself (preset_hit_kernel); -1: none
+    uint32_t launch_flags;   // Photon::flags of a launched photon: its cell << F_CELL_SHIFT, | F_PRESET if there is a preset
+    int32_t n_cells;
+};
+
 // One medium.
 template <typename real>
 struct DevMat {
@@ -174,7 +204,7 @@ struct DevSource {
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, acc, hist, total;
+    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, cells, acc, hist, total;
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
@@ -252,12 +282,15 @@ struct HotScene {
 // FEAT_RUNS (float32): some axis group holds three or more rectangles in one plane (the edge faces of
 // stacked slabs, a segmented read-out); the hit table then lists them as runs behind the plane they
 // share, see RunHdr.
+// FEAT_CELLS (float32, rectangle-only scenes of the world frame; not part of FEAT_ALL): some rectangles close
+// boxes (DevCell); photons inside them find their next element without walking the list, the others wait for a
+// pass of the wave loop that walks it for all of them together.
 // FEAT_HBMHIST (only with everything else): detectors x wavelength bins exceed what the LDS
 // can hold beside the tables; every workgroup then counts hits with atomics in a histogram of
 // its own in HBM (one shared histogram is bounded by the rate of atomics on its few hot
 // words: 2e9 photons/s whatever the scene) and a second kernel adds the copies up.
 enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_BACK = 16, FEAT_FRAMES = 32, FEAT_GUARD = 64,
-             FEAT_HBMHIST = 128, FEAT_RUNS = 256, FEAT_ALL = 511 };
+             FEAT_HBMHIST = 128, FEAT_RUNS = 256, FEAT_ALL = 511, FEAT_CELLS = 512 };
 
 #if defined(__HIPCC__)
 // ---------------------------------------------------------------------------
@@ -442,7 +475,12 @@ struct Photon {
     int32_t iter;
     uint32_t flags;   // F_* bits
 };
-enum : uint32_t { F_ADM_ALL = 1u, F_WAS_EL = 2u, F_REFLECTED = 4u, F_ABS_ONCE = 8u };
+enum : uint32_t { F_ADM_ALL = 1u, F_WAS_EL = 2u, F_REFLECTED = 4u, F_ABS_ONCE = 8u,
+                  // kernels with FEAT_CELLS:
+                  F_PRESET = 32u,    // freshly launched from a strict source: its first hit (best_t, last_el) is the scene's preset
+                  F_OUTBOUND = 128u, // the photon sits on a face of a cell nested in its own and moves away from it
+                  F_CELL_SHIFT = 8u, F_CELL_MASK = 0xFF00u,  // the cell the photon is in (0 = none)
+                  F_CELL_RECORD_SHIFT = 7u, F_CELL_RECORD_MASK = 0x1FFu };  // 2 cell + outbound: the photon's cell record
 template <typename real>
 __device__ __forceinline__ void set_flag(Photon<real> &p, uint32_t bit, bool on)
 {
@@ -462,6 +500,7 @@ struct Lds {
     const uint16_t *bin;   // per wavelength id: compact detector bin
     const uint32_t *run_cells;              // grids of the runs of coplanar rectangles
     const RunMember<real> *run_members;     // their members
+    const CellHeader *cells;                // header, then the DevCell records (record 0 = no cell)
     unsigned long long *acc;
     uint32_t *hist;
 };
@@ -826,7 +865,7 @@ __device__ __forceinline__ void perpendicular(real Dx, real Dy, real Dz, real u_
 // words 0,1 direction, 2 polarisation angle, 3 free path.
 // Launch or re-emission of the lanes of a wave in one pass: the direction and
 // polarisation samplers are run once for both kinds of lane.
-template <bool ALIGNED, bool AREA, bool SPECTRA, typename real>
+template <bool ALIGNED, bool AREA, bool SPECTRA, bool CELLS = false, typename real>
 __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<real> &hot, const Lds<real> &lds,
                                              Photon<real> &p, Rng<real, false> &g, bool launching)
 {
@@ -853,6 +892,12 @@ __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<r
             p.Ly += (g.uniform(1) - real(0.5)) * s.area[1];
         }
         init_photon_common(sc, p);
+        if constexpr (CELLS) {   // the cell the source sits in; a strict source: the first hit, the same for every photon
+            const CellHeader &h = *lds.cells;
+            p.flags = h.launch_flags;
+            p.best_t = h.preset_t;
+            p.last_el = h.preset_e;
+        }
     }
     p.dist = dist;
 }
@@ -1358,6 +1403,87 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
     return nearest;
 }
 
+// The search of a photon that is confined to a cell (kernels with FEAT_CELLS).  Inside a closed
+// axis-aligned box the line leaves through the nearest of the three faces the photon moves towards;
+// the faces behind it lie at the other side of its line parameter and every other element of the
+// scene lies beyond the box (the host only marks cells whose box nothing else touches), so that
+// face is what the walk over the element list (nearest_valid_hit) would return, with the same line
+// parameter: the axis test's p0 * (1/D_k) - L_k/D_k.  "Towards": candidates lie at t adm_q > 0 --
+// ahead of a photon that was emitted or refracted, *behind* one that was reflected (the
+// reference's reflection returns the negative of the mirror direction, PhotonObject.py:150, and
+// its side test then sends the photon backwards along its line).  A lane answers from its cell if
+//   its cell record is usable (DevCell) and the photon is in the box, within a margin;
+//   the nearest face lies on the admissible side (also rules out adm_q = 0: a re-execution in
+//   place, "every candidate"), is not the element the photon sits on, is not tied with another
+//   face (equal distances go to the lower list index: left to the list walk) and the landing point
+//   is in the box, within the margin.
+// Anything else -- a photon in a cell that holds other elements, one that leaked through a seam --
+// gets element -2 and waits for the list walk.  Where the two can differ is what the list walk
+// itself leaves to rounding: a landing point within an ulp of a face's edge, and a face *behind*
+// the photon whose line parameter comes out as a rounding residue of the admissible sign.
+// The conditions narrow the execution mask one compare after the other (see consider_pair_f32).
+__device__ __forceinline__ void confined_hit(const Lds<float> &lds, const Photon<float> &p, float &dnorm, Nearest<float> &out)
+{
+    dnorm = M<float>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
+    // the whole record at once (five 16-byte reads), then selects: left to itself the compiler selects the
+    // address and reads each plane and index on its own, one LDS round trip after the other
+    typedef float __attribute__((ext_vector_type(4))) Quad;
+    const Quad *rec = reinterpret_cast<const Quad *>(&row(reinterpret_cast<const DevCell *>(lds.cells + 1),
+                                                           (int)((p.flags >> F_CELL_RECORD_SHIFT) & F_CELL_RECORD_MASK)));
+    Quad q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4];
+    asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4));
+    const float plo[3] = {q0.x, q0.y, q0.z}, phi[3] = {q0.w, q1.x, q1.y}, cc[3] = {q1.z, q1.w, q2.x}, hw[3] = {q2.y, q2.z, q2.w};
+    // (the element indices travel as bit patterns; each component is copied out before it is reinterpreted)
+    const float fl[3] = {q3.x, q3.y, q3.z}, fh[3] = {q3.w, q4.x, q4.y};
+    const int idlo[3] = {__float_as_int(fl[0]), __float_as_int(fl[1]), __float_as_int(fl[2])};
+    const int idhi[3] = {__float_as_int(fh[0]), __float_as_int(fh[1]), __float_as_int(fh[2])};
+    const float L[3] = {p.Lx, p.Ly, p.Lz}, D[3] = {p.Dx, p.Dy, p.Dz};
+    float t[3], a[3], dL[3], dB[3];
+    int id[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float inv = M<float>::rcp(D[k]), m = -L[k] * inv;
+        const bool up = D[k] * p.adm_q > 0.0f;   // the photon moves towards the high face
+        t[k] = (up ? phi[k] : plo[k]) * inv + m;
+        id[k] = up ? idhi[k] : idlo[k];
+        a[k] = D[k] == 0.0f ? M<float>::inf() : M<float>::abs(t[k]);   // parallel to this pair of faces: it meets neither
+        dL[k] = L[k] - cc[k];
+    }
+    float ab;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(ab) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
+    const float am = __builtin_amdgcn_fmed3f(a[0], a[1], a[2]);
+    float tb = a[1] == ab ? t[1] : t[2];
+    int ib = a[1] == ab ? id[1] : id[2];
+    tb = a[0] == ab ? t[0] : tb;
+    ib = a[0] == ab ? id[0] : ib;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dB[k] = tb * D[k] + dL[k];
+    const float ta = tb * p.adm_q;
+    const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
+    int found = -2;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[lx]|, %[hx]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[ly]|, %[hy]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[lz]|, %[hz]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[bx]|, %[hx]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[by]|, %[hy]\n\t"
+                 "v_cmpx_le_f32_e64 vcc, |%[bz]|, %[hz]\n\t"
+                 "v_cmpx_lt_f32_e32 vcc, 0, %[ta]\n\t"
+                 "v_cmpx_neq_f32_e32 vcc, %[ab], %[am]\n\t"
+                 "v_cmpx_ne_u32_e32 vcc, %[ib], %[skip]\n\t"
+                 "v_mov_b32_e32 %[e], %[ib]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [e] "+v"(found), [sv] "=&s"(saved)
+                 : [lx] "v"(dL[0]), [ly] "v"(dL[1]), [lz] "v"(dL[2]), [bx] "v"(dB[0]), [by] "v"(dB[1]), [bz] "v"(dB[2]),
+                   [hx] "v"(hw[0]), [hy] "v"(hw[1]), [hz] "v"(hw[2]), [ta] "v"(ta), [ab] "v"(ab), [am] "v"(am),
+                   [ib] "v"(ib), [skip] "v"(skip)
+                 : "vcc");
+    const bool preset = (p.flags & F_PRESET) != 0u;   // launched from a strict source: the renew block left the hit on the photon
+    out.t = preset ? p.best_t : tb;
+    out.e = preset ? p.last_el : found;
+}
+
 // The direction updates of PhotonObject.py:150 / :199 and the dot product D.n they and the
 // interface start from.  float32 lets the compiler fuse multiplies and adds.  float64 rounds
 // every operation on its own, and sums a dot product the way numpy does, as the reference's
@@ -1638,7 +1764,8 @@ struct NoTally {
     __device__ __forceinline__ void stamp(int) {}
 };
 
-enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2 };
+enum StepResult { STEP_CONTINUE = 0, STEP_ENDED = 1, STEP_ABSORBED = 2,
+                  STEP_WIDE = 3 };  // FEAT_CELLS: nothing done, the photon waits for a pass that walks the element list
 
 
 // PhotonObject.py:216-233: an absorbed photon moves the rest of its free path
@@ -1707,6 +1834,7 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
     const real sgn = real(sgn_i(-dn));
     const real oDx = p.Dx, oDy = p.Dy, oDz = p.Dz;
     p.oldx = p.Lx; p.oldy = p.Ly; p.oldz = p.Lz;
+    if constexpr ((FEATURES & FEAT_CELLS) != 0) p.flags &= ~F_OUTBOUND;  // (set again below if it holds after this operation)
     // a stale re-execution starts on the plane itself: its old point has no side
     const int side = stale ? 0 : sgn_i(off);
     // every operation first moves the photon onto the plane
@@ -1750,6 +1878,14 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
                 refract_direction(p, r, -dn, sgn, nx, ny, nz);
                 p.mat = other;
                 p.flags &= ~F_REFLECTED;
+                if constexpr ((FEATURES & FEAT_CELLS) != 0) {
+                    // through a face of cell c (whose enclosing cell is `outer`): out of c, into c, or -- for a
+                    // photon that was in neither -- no cell any more
+                    const uint32_t c = ((uint32_t)info >> 16) & 0xFFu, outer = (uint32_t)info >> 24;
+                    const uint32_t cur = (p.flags & F_CELL_MASK) >> F_CELL_SHIFT;
+                    const uint32_t next = c == 0u ? cur : (cur == c ? outer : (cur == outer ? c : 0u));
+                    p.flags = (p.flags & ~F_CELL_MASK) | (next << F_CELL_SHIFT);
+                }
                 if (other_slot >= 0)  // PhotonObject.py:283-305, with E as Reflectance left it
                     p.dist = free_path<ALIGNED>(sc, lds, other, other_slot, p, g.expo(1));
                 else
@@ -1768,6 +1904,13 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
     else rotate_polarization(p, oDx, oDy, oDz, dnorm, reflect, dn, nx, ny, nz);
 #endif
     p.flags |= F_WAS_EL;  // PhotonObject.py:143
+    if constexpr ((FEATURES & FEAT_CELLS) != 0) {
+        // The photon now sits on a face of cell c.  If it is in the cell around c -- refracted out of c, or
+        // reflected off it from outside -- it moves away from c and cannot meet it again before it has met
+        // something else: c is convex.
+        const uint32_t c = ((uint32_t)info >> 16) & 0xFFu, outer = (uint32_t)info >> 24;
+        if (c != 0u && ((p.flags & F_CELL_MASK) >> F_CELL_SHIFT) == outer) p.flags |= F_OUTBOUND;
+    }
     set_admissibility(p, type, side, nx * p.Dx + ny * p.Dy + nz * p.Dz);
     return false;
 }
@@ -1783,9 +1926,13 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
 // lane takes no further step before the caller has dealt with it, and a caller
 // that deals with the lanes of several iterations at once (the renew block of
 // the trace kernel) runs that code once for all of them.
+//
+// Kernels with FEAT_CELLS: `walk_list` (wave-uniform) says how this pass searches -- by walking the
+// element list for every lane in it, or per lane from the cell the photon is confined to; a lane
+// that cannot answer from its cell returns STEP_WIDE with its photon untouched.
 template <int FEATURES, bool DEFER_ENDINGS, typename real, bool TAPE, typename Tally>
 __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, const Lds<real> &lds,
-                                                  Photon<real> &p, Rng<real, TAPE> &g, Tally &tally)
+                                                  Photon<real> &p, Rng<real, TAPE> &g, Tally &tally, bool walk_list = true)
 {
     // the variates of this iteration (every lane computes its block together;
     // which words are used depends on what the iteration turns out to be)
@@ -1793,7 +1940,21 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     g.block((uint32_t)p.iter, BLK_STEP);
     tally.stamp(0);
     real dnorm;
-    const Nearest<real> nearest = nearest_valid_hit<FEATURES>(sc, lds, p, dnorm);
+    Nearest<real> nearest;
+    if constexpr ((FEATURES & FEAT_CELLS) != 0 && sizeof(real) == 4 && !TAPE) {
+        if (walk_list) {
+            nearest = nearest_valid_hit<FEATURES>(sc, lds, p, dnorm);
+        } else {
+            confined_hit(lds, p, dnorm, nearest);
+            if (nearest.e == -2) {
+                tally.stamp(1);
+                return STEP_WIDE;
+            }
+        }
+        p.flags &= ~F_PRESET;
+    } else {
+        nearest = nearest_valid_hit<FEATURES>(sc, lds, p, dnorm);
+    }
     tally.stamp(1);
     const real best_t = nearest.t;
     const int best_e = nearest.e;
@@ -1816,7 +1977,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             p.dist -= p.hitd;
             p.status = RTMC_ST_START;
         } else {
-            p.flags = (p.flags | F_ABS_ONCE) & ~F_WAS_EL;
+            p.flags = (p.flags | F_ABS_ONCE) & ~(F_WAS_EL | F_OUTBOUND);
             p.status = RTMC_ST_ABSORBED;
             if (!DEFER_ENDINGS) finish_absorbed_move(p, tally);
             return STEP_ABSORBED;

@@ -370,6 +370,13 @@ class Scene:
         _abi.check(self.lib.rtmc_scene_info(self.handle, out), self.lib)
         return {"runs": out[0], "run_members": out[1], "guard": out[2], "all_features_kernel": bool(out[3])}
 
+    def cells(self):
+        """The closed boxes among the scene's rectangles: how many, in how many of them photons can be confined,
+        the one the source sits in (0 none), whether the scene runs the kernels that use them."""
+        out = (C.c_int32 * 4)()
+        _abi.check(self.lib.rtmc_scene_cells(self.handle, out), self.lib)
+        return {"cells": out[0], "usable": out[1], "source_cell": out[2], "in_use": bool(out[3])}
+
     def wavelengths(self):
         cnt = C.c_int64()
         _abi.check(self.lib.rtmc_scene_wavelengths(self.handle, C.byref(cnt), None, 0), self.lib)

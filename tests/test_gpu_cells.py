@@ -1,0 +1,101 @@
+"""Closed boxes among a scene's rectangles ("cells") and the search that answers from them.
+
+The reference tries every element on every search (RayTrace.py:128-150).  The float32 kernels
+answer the search of a photon that is inside a closed axis-aligned box, with nothing else in it,
+from the three faces it moves towards; photons elsewhere wait for a pass that walks the list.  The
+answers are the list walk's own (same line parameter, same element) except where the list walk
+itself is decided by rounding -- a landing point within an ulp of an edge -- so the tallies of the
+two differ by a few photons in 1e7, never by more; and float64 (which always walks the list,
+photon for photon with the checker elsewhere in this suite) is followed as closely as before."""
+import numpy as np
+import pytest
+
+import helpers as H
+from raytracer_amd import RayTrace, _abi, configs
+
+pytestmark = pytest.mark.gpu
+
+SCALARS = ("n_photons", "n_internal_converted", "n_dumped", "n_capped", "n_lost")
+
+
+def _scene(job):
+    rt = RayTrace.RayTrace(demo_scene=False)
+    rt.LoadJob(job)
+    return rt, rt.Scene()
+
+
+def _moved(a, b):
+    """Photons that end elsewhere (a moved photon changes two counters)."""
+    d = int(np.abs(a["counter"].astype(np.int64) - b["counter"].astype(np.int64)).sum())
+    d += sum(abs(int(a[k]) - int(b[k])) for k in ("n_internal_converted", "n_capped", "n_lost"))
+    return (d + 1) // 2
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C9", "C1_open", "nested", "twin", "mirror box"])
+def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
+    """The same photon ids with and without cells (RTMC_NO_CELLS): fates differ for at most a few
+    photons in 1e6, every photon is accounted for, and the list walk's stale steps -- photons that slip
+    through a seam and find nothing -- do not increase."""
+    def build():
+        if name == "nested":
+            return _scene(configs.nested_job())
+        if name == "twin":
+            return _scene(configs.twin_job())
+        if name == "mirror box":
+            return _scene(configs.mirror_box_job())
+        rt = H.raytrace_for(name)
+        return rt, rt.Scene()
+    n = 40000 if name == "C1_open" else 4000000
+    _, with_cells = build()
+    monkeypatch.setenv("RTMC_NO_CELLS", "1")
+    _, without = build()
+    monkeypatch.delenv("RTMC_NO_CELLS")
+    try:
+        assert with_cells.cells()["in_use"] and not without.cells()["in_use"]
+        a, b = with_cells.run(n, seed=23), without.run(n, seed=23)
+        assert a["n_photons"] == n and b["n_photons"] == n
+        moved = _moved(a, b)
+        steps = abs(int(a["n_steps"]) - int(b["n_steps"]))
+        print("%s: %d of %d photons end elsewhere with cells; steps differ by %d of %d; stale steps %d (cells) %d (list)"
+              % (name, moved, n, steps, int(b["n_steps"]), int(a["n_stale_steps"]), int(b["n_stale_steps"])))
+        assert moved <= 4 + n // 200000, moved
+        # (a photon that takes another turn between mirrors may live thousands of iterations longer)
+        assert steps <= 10001 * (moved + 1) + int(b["n_steps"]) // 20000, steps
+        if name != "C1_open":     # (there every escaped photon is stale until the cap, either way)
+            assert int(a["n_stale_steps"]) <= int(b["n_stale_steps"]) + 2
+    finally:
+        with_cells.close()
+        without.close()
+
+
+@pytest.mark.parametrize("name", ["nested", "twin", "mirror box"])
+def test_cells_follow_float64_photon_for_photon(name):
+    """Scenes with nested and neighbouring boxes and with mirror walls: the float32 kernels (cells) against the
+    float64 ones (list walk) on the same photons, as closely as the plain slab configurations are."""
+    rt, s = _scene({"nested": configs.nested_job, "twin": configs.twin_job, "mirror box": configs.mirror_box_job}[name]())
+    try:
+        n = 2000000
+        a = s.run(n, seed=5, precision=_abi.F32)
+        b = s.run(n, seed=5, precision=_abi.F64)
+        moved = _moved(a, b)
+        print("%s: %d of %d photons leave float64's fate" % (name, moved, n))
+        assert moved <= n // 100000 + 4, moved
+        assert a["n_photons"] == n and a["n_lost"] == 0
+    finally:
+        s.close()
+
+
+def test_cells_against_checker(oracle_mod):
+    """The nested, the twin and the mirror-box scene against the CPU checker: float64 photon for photon, float32 within
+    a few photons."""
+    for make in (configs.nested_job, configs.twin_job, configs.mirror_box_job):
+        rt, s = _scene(make())
+        try:
+            n = 200000
+            cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=9, threads=8)
+            g64 = s.run(n, seed=9, precision=_abi.F64)
+            g32 = s.run(n, seed=9)
+            assert _moved(g64, cpu) <= 4, _moved(g64, cpu)
+            assert _moved(g32, cpu) <= 8, _moved(g32, cpu)
+        finally:
+            s.close()

@@ -271,7 +271,11 @@ def test_runs_of_coplanar_rectangles_change_no_tally(oracle_mod, monkeypatch, jo
     integers, photon for photon -- the segmented edge read-out, a floor of 35 unequal tiles partly
     covered by larger detectors of the same plane (list order decides, RayTrace.py:134), a stack of
     eight slabs whose side faces share four planes, the segmented read-out turned rigidly out of the
-    world's axes -- and float64 agrees with the checker."""
+    world's axes -- and float64 agrees with the checker.  (Both builds search by walking the
+    element list, RTMC_NO_CELLS: answering from closed boxes instead is compared in
+    tests/test_gpu_cells.py, and is not photon for photon at seams.)"""
+    monkeypatch.setenv("RTMC_NO_CELLS", "1")
+
     def build():
         rt = RayTrace.RayTrace(demo_scene=False)
         if job == "strips":
