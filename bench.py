@@ -276,7 +276,10 @@ def main():
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          "traffic": traffic,
-                         "kernel": "trace_kernel<float, 0>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "kernel": ("trace_kernel<float, FEAT_ALL>" if scene.info()["all_features_kernel"]
+                                    else "trace_kernel<float, %d>" % scene.cells()["kernel_features"]),
+                         "closed_boxes_in_use": scene.cells()["in_use"],
+                         "kernel_ms_avg": avg_kernel_s * 1e3,
                          "flop_per_iteration": flops_per_iteration(n_el),
                          "iterations_per_launch": iters_per_launch,
                          "executed": executed_work(args.config, per_step, avg_kernel_s),

@@ -1883,7 +1883,7 @@ RTMC_API int rtmc_scene_cells(const rtmc_scene *s, int32_t info[4])
     info[0] = s->n_cells;
     info[1] = s->n_cells_usable;
     info[2] = s->start_cell;
-    info[3] = (s->features() & FEAT_CELLS) ? 1 : 0;
+    info[3] = s->features();
     return RTMC_OK;
 }
 

@@ -43,6 +43,6 @@ def test_cells_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("RTMC_NO_CELLS", "1")
     s = H.raytrace_for("C2").Scene()
     try:
-        assert s.cells() == {"cells": 0, "usable": 0, "source_cell": 0, "in_use": False}
+        assert s.cells() == {"cells": 0, "usable": 0, "source_cell": 0, "in_use": False, "kernel_features": 0}
     finally:
         s.close()

@@ -18,7 +18,7 @@ counters = {k: vals[k] for k in ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_I
                                  "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES") if k in vals}
 print(json.dumps({
     **counters,
-    "workload": sys.argv[3], "photons_per_launch": int(sys.argv[2]), "kernel": "trace_kernel<float, 0>",
+    "workload": sys.argv[3], "photons_per_launch": int(sys.argv[2]), "kernel": "trace_kernel<float, …> of the workload (see the bench line)",
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
     "kernel_source_sha256": bench.kernel_source_digest(),
