@@ -272,7 +272,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                     renew_emit_aligned(hot, lds, row(lds.mats, p.mat), p, g, emit_iter);
                 else
                     renew_photon<ALIGNED, (FEATURES & FEAT_AREA) != 0, (FEATURES & FEAT_SPECTRA) != 0, CELLS>(sc, hot, lds, p, g, launching);
-                need = NEED_NONE;
+                need = (CELLS && (p.flags & F_LIST)) ? NEED_WIDE : NEED_NONE;
                 tally.stamp(8);
             }
             SECTION_END(cyc_renew, n_renew, lanes_renew, renew_mask);
@@ -287,8 +287,13 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
             const bool walk_list = waiting != 0ull && (wide_debt >= WIDE_DEBT || __ballot(need == NEED_NONE) == 0ull);
             if (walk_list) wide_debt = 0;
             if (need == NEED_NONE || (walk_list && need == NEED_WIDE)) {
+                const uint32_t record = p.flags & (F_CELL_MASK | F_OUTBOUND);
                 const StepResult r = photon_step<FEATURES, true>(hot, lds, p, g, tally, walk_list);
-                need = r == STEP_ENDED ? NEED_RETIRE : (r == STEP_ABSORBED ? NEED_EMIT : (r == STEP_WIDE ? NEED_WIDE : NEED_NONE));
+                // F_LIST: set when the search from the cell fails, dropped when the photon's cell record changes
+                if (r == STEP_WIDE || (p.flags & F_CELL_MASK) == F_CELL_MASK) p.flags |= F_LIST;   // (cell unknown: for good)
+                else if ((p.flags & (F_CELL_MASK | F_OUTBOUND)) != record) p.flags &= ~F_LIST;
+                need = r == STEP_ENDED ? NEED_RETIRE
+                     : (r == STEP_ABSORBED ? NEED_EMIT : ((p.flags & F_LIST) ? NEED_WIDE : NEED_NONE));
             }
 #ifdef RTMC_PROFILE_SECTIONS
             if (lane == 0) { n_walk += walk_list ? 1 : 0; }
@@ -356,7 +361,7 @@ preset_hit_kernel(const DevScene<float> *scene, CellHeader *hdr)
     if (threadIdx.x == 0 && first.e >= 0) {
         hdr->preset_t = first.t;
         hdr->preset_e = first.e;
-        hdr->launch_flags |= F_PRESET;
+        hdr->launch_flags = (hdr->launch_flags & ~F_LIST) | F_PRESET;
     }
 }
 
@@ -945,7 +950,7 @@ CellPlan find_cells(const rtmc_scene_desc *d)
             b.face[a][1] = find_face(a, b.hi[a], b.lo, b.hi);
             closed = b.face[a][0] >= 0 && b.face[a][1] >= 0;
         }
-        if (closed && boxes.size() < 254) boxes.push_back(b);
+        if (closed && boxes.size() < 254) boxes.push_back(b);   // (cell numbers 1..254; 255 = unknown)
     }
     // a rectangle that is a face of two boxes (two boxes sharing a wall) would have to move a photon between
     // three cells: neither box becomes a cell
@@ -1468,7 +1473,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         CellHeader hdr;
         memset(&hdr, 0, sizeof hdr);
         hdr.preset_e = -1;
-        hdr.launch_flags = (uint32_t)plan.start_cell << F_CELL_SHIFT;   // (F_PRESET: set on the device, see preset_hit_kernel)
+        // (F_PRESET is set on the device, see preset_hit_kernel, which then drops F_LIST)
+        hdr.launch_flags = ((uint32_t)plan.start_cell << F_CELL_SHIFT) | (plan.cells[2 * plan.start_cell].hw[0] < 0.0f ? F_LIST : 0u);
         hdr.n_cells = (int32_t)plan.cells.size() / 2 - 1;
         memcpy(img.lds.data() + lay.cells, &hdr, sizeof hdr);
         memcpy(img.lds.data() + lay.cells + sizeof hdr, plan.cells.data(), sizeof(DevCell) * plan.cells.size());

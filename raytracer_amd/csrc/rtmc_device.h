@@ -150,7 +150,8 @@ static_assert(sizeof(DevCell) == 80, "five 16-byte LDS reads per lane");
 struct alignas(16) CellHeader {
     float preset_t;          // strict source: line parameter and element of the first hit of every photon,
     int32_t preset_e;        //   found once per scene by the search itself (preset_hit_kernel); -1: none
-    uint32_t launch_flags;   // Photon::flags of a launched photon: its cell << F_CELL_SHIFT, | F_PRESET if there is a preset
+    uint32_t launch_flags;   // Photon::flags of a launched photon: its cell << F_CELL_SHIFT, | F_PRESET if there is a preset,
+                             // | F_LIST if there is none and the source's cell is no place for a confined search
     int32_t n_cells;
 };
 
@@ -480,8 +481,13 @@ struct Photon {
 enum : uint32_t { F_ADM_ALL = 1u, F_WAS_EL = 2u, F_REFLECTED = 4u, F_ABS_ONCE = 8u,
                   // kernels with FEAT_CELLS:
                   F_PRESET = 32u,    // freshly launched from a strict source: its first hit (best_t, last_el) is the scene's preset
+                  F_LIST = 64u,      // the photon's last search from its cell failed and its cell record has not changed since:
+                                     // the next one walks the list without trying (a photon outside every cell would
+                                     // otherwise spend every other pass of the loop on a search that cannot succeed)
                   F_OUTBOUND = 128u, // the photon sits on a face of a cell nested in its own and moves away from it
-                  F_CELL_SHIFT = 8u, F_CELL_MASK = 0xFF00u,  // the cell the photon is in (0 = none)
+                  F_CELL_SHIFT = 8u, F_CELL_MASK = 0xFF00u,  // the cell the photon is in (0 = none; 255 = unknown for the rest of its
+                                                             // life: it walks the list, see F_LIST)
+                  CELL_UNKNOWN = 255u,
                   F_CELL_RECORD_SHIFT = 7u, F_CELL_RECORD_MASK = 0x1FFu };  // 2 cell + outbound: the photon's cell record
 template <typename real>
 __device__ __forceinline__ void set_flag(Photon<real> &p, uint32_t bit, bool on)
@@ -1882,10 +1888,10 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
                 p.flags &= ~F_REFLECTED;
                 if constexpr ((FEATURES & FEAT_CELLS) != 0) {
                     // through a face of cell c (whose enclosing cell is `outer`): out of c, into c, or -- for a
-                    // photon that was in neither -- no cell any more
+                    // photon that was in neither -- not known any more
                     const uint32_t c = ((uint32_t)info >> 16) & 0xFFu, outer = (uint32_t)info >> 24;
                     const uint32_t cur = (p.flags & F_CELL_MASK) >> F_CELL_SHIFT;
-                    const uint32_t next = c == 0u ? cur : (cur == c ? outer : (cur == outer ? c : 0u));
+                    const uint32_t next = c == 0u ? cur : (cur == c ? outer : (cur == outer ? c : CELL_UNKNOWN));
                     p.flags = (p.flags & ~F_CELL_MASK) | (next << F_CELL_SHIFT);
                 }
                 if (other_slot >= 0)  // PhotonObject.py:283-305, with E as Reflectance left it
@@ -1946,6 +1952,10 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
     if constexpr ((FEATURES & FEAT_CELLS) != 0 && sizeof(real) == 4 && !TAPE) {
         if (walk_list) {
             nearest = nearest_valid_hit<FEATURES>(sc, lds, p, dnorm);
+            // nothing found: the photon is in the open, outside every closed box.  What the reference does with it
+            // from here on (the last operation again and again, in place, which also flips its medium,
+            // RayTrace.py:124-154) has no geometric meaning that a cell number could follow.
+            if (nearest.e < 0) p.flags |= F_CELL_MASK;
         } else {
             confined_hit(lds, p, dnorm, nearest);
             if (nearest.e == -2) {
