@@ -161,6 +161,9 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=1.5e8)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo to rehearse N ranks on one GPU)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal only)")
+    ap.add_argument("--also", default="C3:2e9,C4:2e9,C5:4e9",
+                    help="single-GPU runs only: further BASELINE configurations traced once each after the timed "
+                         "region (name:photons, comma separated; empty: none); reported as other_configs")
     ap.add_argument("--dump-tallies", default=None,
                     help="rank 0 writes the summed tallies of the timed steps to this .npz (tests)")
     args = ap.parse_args()
@@ -291,6 +294,8 @@ def main():
                                  "photon_record_bytes_kept_in_registers": 96}},
             "collective": distributed.collective_info(block),
         }
+        if world == 1 and args.also and args.config == "C2" and not strong:
+            out["other_configs"] = other_configs(args.also, args.seed, device)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rt, int(args.cpu_sample), args.seed, args.config)
         print(json.dumps(out), flush=True)
@@ -298,6 +303,35 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def other_configs(spec, seed, device):
+    """The other BASELINE configurations (co-doped slab with donor -> acceptor transfer, stacked slabs with
+    reflective edges, sun-spectrum source) traced once each on this GPU, outside the timed region of the
+    headline workload: photons/s by the kernel time of one launch, with what identifies the run."""
+    from raytracer_amd import RayTrace, configs
+    result = {}
+    for item in spec.split(","):
+        name, _, count = item.partition(":")
+        n = int(float(count or 1e9))
+        rt = RayTrace.RayTrace(demo_scene=False)
+        rt.LoadJob(configs.make_job(name, n))
+        s = rt.Scene()
+        try:
+            s.run(1000000, seed=seed + 1, device=device)                  # scene upload and code object
+            t0 = time.perf_counter()
+            t = s.run(n, seed=seed, device=device)
+            wall = time.perf_counter() - t0
+            edges = [2, 8, 14] if name == "C4" else [2, 3, 4, 5]       # C4: the one detector edge of each of its slabs
+            result[name] = {"photons": n, "photons_per_s": n / (s.last_kernel_ms(device) * 1e-3),
+                            "photons_per_s_wall": n / wall, "kernel_ms": s.last_kernel_ms(device),
+                            "iterations_per_photon": t["n_steps"] / t["n_photons"],
+                            "optical_efficiency": float(t["counter"][edges].sum()) / t["n_photons"],
+                            "every_photon_has_a_fate": bool(t["n_photons"] == n),
+                            "closed_boxes_in_use": s.cells()["in_use"]}
+        finally:
+            s.close()
+    return result
 
 
 def cpu_baseline(rt, sample, seed, config):
