@@ -425,6 +425,67 @@ def mirror_box_job(n_photons=10):
     return job
 
 
+def random_boxes_job(seed, n_photons=10):
+    """Random axis-aligned scene for the closed-box search: one to three dye slabs of random size at random,
+    non-overlapping places (stacked with gaps or side by side) inside a detector box that may have mirror
+    walls, random edge types (detector, mirror), sometimes a second box around everything, sometimes a loose
+    mirror or detector in the shell; strict or hemispherical source above the first slab."""
+    rng = np.random.RandomState(7000 + seed)
+    els, props, sizes = [], [], []
+    n_slabs = int(rng.randint(1, 4))
+    stacked = rng.rand() < 0.5
+    names = ["LR", "LRO"]
+    z_top = 0.0
+    x_next = -3.0
+    first = None
+    for k in range(n_slabs):
+        hx, hy = float(rng.randint(4, 11)) / 8.0, float(rng.randint(6, 13)) / 8.0
+        th = float(rng.randint(1, 7)) / 16.0
+        if stacked:
+            cx, cy = 0.0, 0.0
+            z1 = z_top
+            z0 = z1 - th
+            z_top = z0 - float(rng.randint(1, 5)) / 32.0
+        else:
+            cx, cy = x_next + hx, float(rng.randint(-2, 3)) / 8.0
+            x_next = cx + hx + float(rng.randint(1, 5)) / 16.0
+            z1 = float(rng.randint(-2, 3)) / 16.0
+            z0 = z1 - th
+        zc, hw = 0.5 * (z0 + z1), 0.5 * (z1 - z0)
+        mat = names[int(rng.randint(0, 2))]
+        e = [[[cx, cy, z0], [0.0, 0.0, 1.0]], [[cx, cy, z1], [0.0, 0.0, 1.0]],
+             [[cx + hx, cy, zc], [-1.0, 0.0, 0.0]], [[cx - hx, cy, zc], [1.0, 0.0, 0.0]],
+             [[cx, cy + hy, zc], [0.0, -1.0, 0.0]], [[cx, cy - hy, zc], [0.0, 1.0, 0.0]]]
+        pr = [[2, mat, "air"], [2, "air", mat]]
+        for _ in range(4):
+            pr.append([4, 0, 0, ""] if rng.rand() < 0.6 else [1])
+        sz = [[hx, hy], [hx, hy], [hy, hw], [hy, hw], [hx, hw], [hx, hw]]
+        els, props, sizes = els + e, props + pr, sizes + sz
+        if first is None:
+            first = (cx, cy, z1)
+    e2, p2, s2 = _dump_box(0.0, 0.0, -0.5, 5.0, 2.0)
+    for k in range(5):                      # the floor stays a detector: every photon ends somewhere
+        if rng.rand() < 0.3:
+            p2[k] = [1]
+    els, props, sizes = els + e2, props + p2, sizes + s2
+    if rng.rand() < 0.3:
+        e3, p3, s3 = _dump_box(0.0, 0.0, -0.5, 6.5, 3.0)
+        els, props, sizes = els + e3, props + p3, sizes + s3
+    geometry = [1] * len(els)
+    if rng.rand() < 0.3:                    # something loose in the shell: the box around it is no place for a confined search
+        els.append([[3.5, -3.0, 1.0], [0.0, 0.0, 1.0]])
+        props.append([1] if rng.rand() < 0.5 else [4, 0, 0, ""])
+        sizes.append([0.5, 0.75])
+        geometry.append(1)
+    mats = [copy.deepcopy(AIR_ROW), dye_row("LR"), dye_row("LRO", conc_b=1.0)]
+    strict = rng.rand() < 0.5
+    direction = (float(rng.randint(-3, 4)) / 16.0, float(rng.randint(-3, 4)) / 16.0, -1.0) if strict else (0.0, 0.0, -1.0)
+    start = (first[0] + float(rng.randint(-2, 3)) / 16.0, first[1] + float(rng.randint(-2, 3)) / 16.0, first[2] + 0.75)
+    photon = _photon(n_photons, start, STRICT if strict else ISOTROPIC, FIXED_WL, 460, "air", direction)
+    return {"Elements": np.array(els, dtype=np.float64), "ElementProperties": props, "ElementGeometry": geometry,
+            "ElementSize": sizes, "Materials": mats, "Photon": photon}
+
+
 def synthetic_am15():
     """Two-column stand-in for the sun table the reference expects in
     `AM15.txt` (reference PhotonObject.py:41; the file is not distributed with

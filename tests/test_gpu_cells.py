@@ -99,3 +99,29 @@ def test_cells_against_checker(oracle_mod):
             assert _moved(g32, cpu) <= 8, _moved(g32, cpu)
         finally:
             s.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_boxes(oracle_mod, monkeypatch, seed):
+    """Random slabs in random boxes (configs.random_boxes_job): the float64 kernels photon for photon with the
+    checker, float32 with cells within a few photons of float64, and of float32 without cells."""
+    n = 300000
+    rt, s = _scene(configs.random_boxes_job(seed, 10))
+    monkeypatch.setenv("RTMC_NO_CELLS", "1")
+    _, without = _scene(configs.random_boxes_job(seed, 10))
+    monkeypatch.delenv("RTMC_NO_CELLS")
+    try:
+        cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=100 + seed, threads=8)
+        g64 = s.run(n, seed=100 + seed, precision=_abi.F64)
+        g32 = s.run(n, seed=100 + seed)
+        plain = without.run(n, seed=100 + seed)
+        c = s.cells()
+        print("random boxes %d: %d elements, cells %s; moved f64/checker %d, f32/f64 %d, cells/list %d of %d"
+              % (seed, s.n_elements, c, _moved(g64, cpu), _moved(g32, g64), _moved(g32, plain), n))
+        assert g32["n_photons"] == n and g32["n_lost"] == 0
+        assert _moved(g64, cpu) <= 4
+        assert _moved(g32, g64) <= 6
+        assert _moved(g32, plain) <= 4
+    finally:
+        s.close()
+        without.close()
