@@ -522,6 +522,10 @@ CONFIGS = {
     "C2r": (rotated_job, dict(base="C2")),
     "C9": (slab_job, dict(thickness=0.3, enclosed=True, donor=True, eqe=EQE_DEMO, scale=2.0,
                           fix_dist=True, fix_dist_r=3.0)),
+    # C2 with every edge of the slab read out by 3 / 14 detectors side by side, and a stack of eight slabs
+    "S3": (strip_job, dict(strips=3)),
+    "S14": (strip_job, dict(strips=14)),
+    "stack8": (stacked_job, dict(n_slabs=8)),
 }
 
 

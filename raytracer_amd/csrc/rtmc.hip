@@ -77,6 +77,7 @@ __device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char 
     l.run_cells = reinterpret_cast<const uint32_t *>(smem + sc.lay.run_cells);
     l.run_members = reinterpret_cast<const RunMember<real> *>(smem + sc.lay.run_members);
     l.cells = reinterpret_cast<const CellHeader *>(smem + sc.lay.cells);
+    l.tile_grids = reinterpret_cast<const TileGrid *>(smem + sc.lay.tile_grids);
     l.acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
     l.hist = reinterpret_cast<uint32_t *>(smem + sc.lay.hist);
     return l;
@@ -343,6 +344,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
 // kernels with cells take it from the header of the cell table instead of walking the element
 // list; this kernel, run once when a scene is uploaded, finds it with that very walk (one wave, all
 // lanes alike) and marks the launch flags if there is a hit.
+template <bool RUNS>
 __global__ void __launch_bounds__(64)
 preset_hit_kernel(const DevScene<float> *scene, CellHeader *hdr)
 {
@@ -357,7 +359,7 @@ preset_hit_kernel(const DevScene<float> *scene, CellHeader *hdr)
     p.wid = sc.src.wid_fixed;
     init_photon_common(sc, p);
     float dnorm;
-    const Nearest<float> first = nearest_valid_hit<0>(hot, lds, p, dnorm);
+    const Nearest<float> first = nearest_valid_hit<RUNS ? FEAT_RUNS : 0>(hot, lds, p, dnorm);
     if (threadIdx.x == 0 && first.e >= 0) {
         hdr->preset_t = first.t;
         hdr->preset_e = first.e;
@@ -755,6 +757,7 @@ struct DeviceImage {
     int n_group[4];
     bool has_runs = false;           // some axis group lists coplanar rectangles as runs (float32 only)
     int n_runs = 0, n_run_members = 0;
+    int n_tiled_faces = 0;           // faces of cells that are tilings looked up through a grid (float32 only)
     std::vector<unsigned char> lds;  // elems | mats | abs | cdf
     LdsLayout lay;
     DevSource<real> src;
@@ -768,6 +771,11 @@ struct CellPlan {
     std::vector<uint8_t> el_outer;       //              and the cell around that one (0 none)
     int start_cell = 0;                  // innermost cell that holds the source
     int n_usable = 0;                    // cells in which some photon can be confined (leaf or simple)
+    // faces that are tilings: per tiled face its rectangles in list order, in the in-plane coordinates of the hit
+    // table (axes k+1, k+2 of normal axis k); DevCell::idlo/idhi name list g as -(g + 2)
+    struct Tile { double ci, cj, hi, hj; int index; };
+    std::vector<std::vector<Tile>> tiles;
+    std::vector<int> tile_owner;         // the cell each tiled face belongs to
 };
 
 struct PerDevice {
@@ -847,16 +855,22 @@ struct rtmc_scene {
     bool hist_in_hbm = false;       // detectors x bins too large for the LDS in some precision
     bool has_runs = false;          // the float32 hit table lists coplanar rectangles as runs
     bool has_cells = false;         // some rectangles close boxes in which photons can be confined (float32)
+    bool has_tiles = false;         // some face of such a box is a tiling of several rectangles
     int n_cells = 0, n_cells_usable = 0, start_cell = 0;
     int features() const
     {
-        if (has_area || has_coplanar || seam_source || hist_in_hbm) return FEAT_ALL;
+        if (has_area || has_coplanar || seam_source || (hist_in_hbm && !cells_in_use())) return FEAT_ALL;
         return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES | FEAT_FRAMES : 0) |
                (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0) |
-               (has_runs ? FEAT_RUNS : 0) | (cells_in_use() ? FEAT_CELLS : 0);
+               ((has_runs || ((has_tiles || hist_in_hbm) && cells_in_use())) ? FEAT_RUNS : 0) |
+               (cells_in_use() ? FEAT_CELLS : 0) | (hist_in_hbm ? FEAT_HBMHIST : 0);
     }
-    // the kernels with cells exist for rectangle-only scenes of the world frame without runs
-    bool cells_in_use() const { return has_cells && !has_shapes && !has_frames && !has_runs; }
+    // the kernels with cells exist for rectangle-only scenes of the world frame; those that also hold the code for
+    // runs of coplanar rectangles, tiled faces and the detector histogram in HBM, for isotropic dyes only
+    bool cells_in_use() const
+    {
+        return has_cells && !has_shapes && !has_frames && !((has_runs || has_tiles || hist_in_hbm) && has_aligned);
+    }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
     std::vector<uint32_t> eqeT;     // [n_eqe][n_wid]
@@ -874,11 +888,13 @@ struct rtmc_scene {
 
 namespace {
 
-// Finds the cells of a scene: sets of six rectangles of the world frame (normal and in-plane axes
-// exactly along the coordinate axes) that close a box, each face spanning exactly the box.  A cell
-// is usable for the confined search if nothing but its faces comes near its box (CELL_LEAF), or if
-// everything that does belongs to one cell nested in it (CELL_SIMPLE).  Lenses are no faces (a
-// photon passes them without the refraction that moves it from cell to cell).
+// Finds the cells of a scene: rectangles of the world frame (normal and in-plane axes exactly along
+// the coordinate axes) that close a box.  A face of the box is one rectangle that spans exactly the
+// box, or several that tile it without gap or overlap (a read-out cut into strips); at least one
+// pair of opposite faces must be whole rectangles.  A cell is usable for the confined search if
+// nothing but its faces comes near its box, or if everything that does belongs to one cell nested in
+// it (see DevCell).  Lenses are no faces (a photon passes them without the refraction that moves it
+// from cell to cell).
 CellPlan find_cells(const rtmc_scene_desc *d)
 {
     CellPlan plan;
@@ -902,6 +918,7 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         return k;
     };
     std::vector<Face> faces[3];
+    std::vector<int> face_slot(n_el, -1);   // position of an element in faces[axis]
     double scale = 1.0;
     for (int i = 0; i < n_el; i++) {
         const rtmc_element &e = d->elements[i];
@@ -914,53 +931,81 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         f.el = i; f.axis = kn; f.p = e.support[kn];
         for (int a = 0; a < 3; a++) { f.c[a] = e.support[a]; f.h[a] = 0; }
         f.h[k1] = e.half1; f.h[k2] = e.half2;
+        face_slot[i] = (int)faces[kn].size();
         faces[kn].push_back(f);
     }
     const double tol = 1e-9 * scale;
-    struct Box { double lo[3], hi[3]; int face[3][2]; bool dropped = false; int parent = -1; };
+    struct Box { double lo[3], hi[3]; std::vector<int> face[3][2]; bool dropped = false; int parent = -1; };
     std::vector<Box> boxes;
     auto near = [&](double a, double b) { return std::fabs(a - b) <= tol; };
-    // the face of `axis` at plane `p` that spans exactly lo..hi along the other two axes; -2 if there are several
+    // the rectangles of `axis` at plane `p` that make up the face lo..hi: one that spans it exactly, or several
+    // that lie inside it, do not overlap and add up to its area; empty if there is no such set
     auto find_face = [&](int axis, double p, const double *lo, const double *hi) {
-        int found = -1;
+        std::vector<int> inside;
+        const int i = (axis + 1) % 3, j = (axis + 2) % 3;
         for (const Face &f : faces[axis]) {
             if (!near(f.p, p)) continue;
-            bool spans = true;
-            for (int a = 0; a < 3; a++)
-                if (a != axis) spans = spans && near(f.c[a] - f.h[a], lo[a]) && near(f.c[a] + f.h[a], hi[a]);
-            if (!spans) continue;
-            if (found >= 0) return -2;
-            found = f.el;
+            if (f.c[i] - f.h[i] < lo[i] - tol || f.c[i] + f.h[i] > hi[i] + tol || f.c[j] - f.h[j] < lo[j] - tol ||
+                f.c[j] + f.h[j] > hi[j] + tol) continue;
+            inside.push_back(f.el);
         }
-        return found;
+        if (inside.empty() || inside.size() > 255) return std::vector<int>();
+        double area = 0;
+        for (size_t a = 0; a < inside.size(); a++) {
+            const Face &fa = faces[axis][face_slot[inside[a]]];
+            area += 4.0 * fa.h[i] * fa.h[j];
+            for (size_t b = a + 1; b < inside.size(); b++) {   // interiors must not overlap
+                const Face &fb = faces[axis][face_slot[inside[b]]];
+                if (std::fabs(fa.c[i] - fb.c[i]) < fa.h[i] + fb.h[i] - tol && std::fabs(fa.c[j] - fb.c[j]) < fa.h[j] + fb.h[j] - tol)
+                    return std::vector<int>();
+            }
+        }
+        const double whole = (hi[i] - lo[i]) * (hi[j] - lo[j]);
+        if (std::fabs(area - whole) > 1e-9 * whole) return std::vector<int>();
+        return inside;
     };
-    for (const Face &A : faces[0]) {
-        // the nearest face above A with the same outline closes the box along x
-        const Face *B = nullptr;
-        for (const Face &o : faces[0])
-            if (o.p > A.p + tol && near(o.c[1], A.c[1]) && near(o.c[2], A.c[2]) && near(o.h[1], A.h[1]) && near(o.h[2], A.h[2]) &&
-                (!B || o.p < B->p)) B = &o;
-        if (!B) continue;
-        Box b;
-        b.lo[0] = A.p; b.hi[0] = B->p;
-        for (int a = 1; a < 3; a++) { b.lo[a] = A.c[a] - A.h[a]; b.hi[a] = A.c[a] + A.h[a]; }
-        bool closed = true;
-        for (int a = 0; a < 3 && closed; a++) {
-            b.face[a][0] = find_face(a, b.lo[a], b.lo, b.hi);
-            b.face[a][1] = find_face(a, b.hi[a], b.lo, b.hi);
-            closed = b.face[a][0] >= 0 && b.face[a][1] >= 0;
+    for (int ax = 0; ax < 3; ax++) {
+        const int i = (ax + 1) % 3, j = (ax + 2) % 3;
+        for (const Face &A : faces[ax]) {
+            // the nearest face above A with the same outline closes the box along this axis
+            const Face *B = nullptr;
+            for (const Face &o : faces[ax])
+                if (o.p > A.p + tol && near(o.c[i], A.c[i]) && near(o.c[j], A.c[j]) && near(o.h[i], A.h[i]) && near(o.h[j], A.h[j]) &&
+                    (!B || o.p < B->p)) B = &o;
+            if (!B) continue;
+            Box b;
+            b.lo[ax] = A.p; b.hi[ax] = B->p;
+            b.lo[i] = A.c[i] - A.h[i]; b.hi[i] = A.c[i] + A.h[i];
+            b.lo[j] = A.c[j] - A.h[j]; b.hi[j] = A.c[j] + A.h[j];
+            bool known = false;
+            for (const Box &o : boxes) {
+                bool same = true;
+                for (int k = 0; k < 3; k++) same = same && near(o.lo[k], b.lo[k]) && near(o.hi[k], b.hi[k]);
+                known = known || same;
+            }
+            if (known) continue;
+            bool closed = true;
+            for (int a = 0; a < 3 && closed; a++) {
+                b.face[a][0] = find_face(a, b.lo[a], b.lo, b.hi);
+                b.face[a][1] = find_face(a, b.hi[a], b.lo, b.hi);
+                closed = !b.face[a][0].empty() && !b.face[a][1].empty();
+            }
+            if (closed && boxes.size() < 254) boxes.push_back(b);   // (cell numbers 1..254; 255 = unknown)
         }
-        if (closed && boxes.size() < 254) boxes.push_back(b);   // (cell numbers 1..254; 255 = unknown)
     }
-    // a rectangle that is a face of two boxes (two boxes sharing a wall) would have to move a photon between
-    // three cells: neither box becomes a cell
+    // a rectangle that is (part of) a face of two boxes (two boxes sharing a wall) would have to move a photon
+    // between three cells: neither box becomes a cell
     {
         std::vector<int> uses(n_el, 0);
         for (const Box &b : boxes)
-            for (int a = 0; a < 3; a++) { uses[b.face[a][0]]++; uses[b.face[a][1]]++; }
+            for (int a = 0; a < 3; a++)
+                for (int side = 0; side < 2; side++)
+                    for (int e : b.face[a][side]) uses[e]++;
         for (Box &b : boxes)
             for (int a = 0; a < 3; a++)
-                if (uses[b.face[a][0]] > 1 || uses[b.face[a][1]] > 1) b.dropped = true;
+                for (int side = 0; side < 2; side++)
+                    for (int e : b.face[a][side])
+                        if (uses[e] > 1) b.dropped = true;
         boxes.erase(std::remove_if(boxes.begin(), boxes.end(), [](const Box &b) { return b.dropped; }), boxes.end());
     }
     if (boxes.empty()) return plan;
@@ -980,7 +1025,9 @@ CellPlan find_cells(const rtmc_scene_desc *d)
                 boxes[i].parent = j;
     std::vector<int> face_of(n_el, -1);
     for (int i = 0; i < n_box; i++)
-        for (int a = 0; a < 3; a++) { face_of[boxes[i].face[a][0]] = i; face_of[boxes[i].face[a][1]] = i; }
+        for (int a = 0; a < 3; a++)
+            for (int side = 0; side < 2; side++)
+                for (int e : boxes[i].face[a][side]) face_of[e] = i;
     // bounding box of any element
     auto bounds = [&](const rtmc_element &e, double *lo, double *hi) {
         for (int a = 0; a < 3; a++) {
@@ -1023,9 +1070,28 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         DevCell c;
         memset(&c, 0, sizeof c);
         for (int k = 0; k < 3; k++) {
-            c.plo[k] = (float)d->elements[b.face[k][0]].support[k];
-            c.phi[k] = (float)d->elements[b.face[k][1]].support[k];
-            c.idlo[k] = b.face[k][0]; c.idhi[k] = b.face[k][1];
+            int32_t *ids[2] = {&c.idlo[k], &c.idhi[k]};
+            float *plane[2] = {&c.plo[k], &c.phi[k]};
+            for (int side = 0; side < 2; side++) {
+                const std::vector<int> &f = b.face[k][side];
+                *plane[side] = (float)d->elements[f[0]].support[k];
+                for (int e : f)   // (tiles of one plane must share its float32 coordinate, as the hit table's runs do)
+                    if ((float)d->elements[e].support[k] != *plane[side]) fits = false;
+                if (f.size() == 1) {
+                    *ids[side] = f[0];
+                } else {   // a tiled face: its rectangles as the hit table describes them, looked up through a grid
+                    *ids[side] = -((int32_t)plan.tiles.size() + 2);
+                    const int ai = (k + 1) % 3, aj = (k + 2) % 3;
+                    std::vector<CellPlan::Tile> list;
+                    for (int e : f) {
+                        const Face &fe = faces[k][face_slot[e]];
+                        list.push_back({fe.c[ai], fe.c[aj], fe.h[ai], fe.h[aj], e});
+                    }
+                    std::sort(list.begin(), list.end(), [](const CellPlan::Tile &x, const CellPlan::Tile &y) { return x.index < y.index; });
+                    plan.tiles.push_back(list);
+                    plan.tile_owner.push_back(1 + i);
+                }
+            }
             c.c[k] = (float)(0.5 * (b.lo[k] + b.hi[k]));
             c.hw[k] = (float)(0.5 * (b.hi[k] - b.lo[k]) + 1e-5 * extent(b));
             if (!(c.plo[k] < c.phi[k])) fits = false;   // (a box float32 cannot resolve)
@@ -1037,10 +1103,11 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         plan.cells[2 * (1 + i) + 1] = (leaf || simple) ? c : unusable;
         if (leaf || simple) plan.n_usable++;
         for (int k = 0; k < 3; k++)
-            for (int side = 0; side < 2; side++) {
-                plan.el_cell[b.face[k][side]] = (uint8_t)(1 + i);
-                plan.el_outer[b.face[k][side]] = (uint8_t)(b.parent < 0 ? 0 : 1 + b.parent);
-            }
+            for (int side = 0; side < 2; side++)
+                for (int e : b.face[k][side]) {
+                    plan.el_cell[e] = (uint8_t)(1 + i);
+                    plan.el_outer[e] = (uint8_t)(b.parent < 0 ? 0 : 1 + b.parent);
+                }
     }
     // the innermost box that holds the source, clear of its faces
     int start = -1;
@@ -1310,6 +1377,33 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
             }
         img.n_run_members = (int)run_members.size();
     }
+    // tiled faces of cells: each gets the grid of a run (float32 image only); a tiling the grid cannot hold
+    // (more than RUN_CELL_SLOTS rectangles crowd one grid cell) makes its cell unusable
+    std::vector<DevCell> cells = plan.cells;
+    std::vector<TileGrid> tile_grids(std::max<size_t>(1, plan.tiles.size()));
+    memset(tile_grids.data(), 0, sizeof(TileGrid) * tile_grids.size());
+    img.n_tiled_faces = 0;
+    if (sizeof(real) == 4) {
+        for (size_t g = 0; g < plan.tiles.size(); g++) {
+            std::vector<HitRec<real>> members;
+            for (const CellPlan::Tile &t : plan.tiles[g]) {
+                HitRec<real> h;
+                memset(&h, 0, sizeof h);
+                h.ci = (real)t.ci; h.cj = (real)t.cj; h.hi = (real)t.hi; h.hj = (real)t.hj; h.index = t.index;
+                members.push_back(h);
+            }
+            Run r;
+            if (build_run(members, r)) {
+                TileGrid &o = tile_grids[g];
+                o.gi0 = (float)r.hdr.gi0; o.gj0 = (float)r.hdr.gj0; o.inv_wi = (float)r.hdr.inv_wi; o.inv_wj = (float)r.hdr.inv_wj;
+                o.ni_1 = r.hdr.ni_1; o.nj_1 = r.hdr.nj_1; o.cell_off = r.hdr.cell_off; o.mem_off = r.hdr.mem_off;
+                img.n_tiled_faces++;
+            } else {
+                for (int rec = 0; rec < 2; rec++)
+                    for (int k = 0; k < 3; k++) cells[2 * plan.tile_owner[g] + rec].hw[k] = -1.0f;
+            }
+        }
+    }
     auto group_count = [&](size_t fi, int k) {
         return (int)(frames[fi].group[k].size() / HIT_CHUNK) | ((int)runs[fi * 3 + k].size() << 16);
     };
@@ -1444,7 +1538,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.bin = (uint32_t)off; off = align(off + 2 * wid_cbin.size());
     lay.run_cells = (uint32_t)off; off = align(off + 4 * run_cells.size());
     lay.run_members = (uint32_t)off; off = align(off + sizeof(RunMember<real>) * run_members.size());
-    lay.cells = (uint32_t)off; off = align(off + sizeof(CellHeader) + sizeof(DevCell) * plan.cells.size());
+    lay.cells = (uint32_t)off; off = align(off + sizeof(CellHeader) + sizeof(DevCell) * cells.size());
+    lay.tile_grids = (uint32_t)off; off = align(off + sizeof(TileGrid) * tile_grids.size());
     lay.acc = (uint32_t)off;
     lay.n_wid = (uint32_t)n_wid;
     lay.n_bins = (uint32_t)n_bins;
@@ -1474,10 +1569,11 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         memset(&hdr, 0, sizeof hdr);
         hdr.preset_e = -1;
         // (F_PRESET is set on the device, see preset_hit_kernel, which then drops F_LIST)
-        hdr.launch_flags = ((uint32_t)plan.start_cell << F_CELL_SHIFT) | (plan.cells[2 * plan.start_cell].hw[0] < 0.0f ? F_LIST : 0u);
-        hdr.n_cells = (int32_t)plan.cells.size() / 2 - 1;
+        hdr.launch_flags = ((uint32_t)plan.start_cell << F_CELL_SHIFT) | (cells[2 * plan.start_cell].hw[0] < 0.0f ? F_LIST : 0u);
+        hdr.n_cells = (int32_t)cells.size() / 2 - 1;
         memcpy(img.lds.data() + lay.cells, &hdr, sizeof hdr);
-        memcpy(img.lds.data() + lay.cells + sizeof hdr, plan.cells.data(), sizeof(DevCell) * plan.cells.size());
+        memcpy(img.lds.data() + lay.cells + sizeof hdr, cells.data(), sizeof(DevCell) * cells.size());
+        memcpy(img.lds.data() + lay.tile_grids, tile_grids.data(), sizeof(TileGrid) * tile_grids.size());
     }
 
     const rtmc_source &s = d->source;
@@ -1782,6 +1878,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     const CellPlan plan = find_cells(d);
     s->has_cells = plan.n_usable > 0;
     s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
+    s->has_tiles = !plan.tiles.empty();
     build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, plan, s->img32);
     build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, plan, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
@@ -1849,10 +1946,27 @@ static const void *trace_variant(int features)
 template <typename real>
 static const void *trace_function(int features)
 {
-    if (features & (FEAT_AREA | FEAT_GUARD | FEAT_HBMHIST)) return (const void *)trace_kernel<real, FEAT_ALL>;
+    if (features & (FEAT_AREA | FEAT_GUARD)) return (const void *)trace_kernel<real, FEAT_ALL>;
+    if (features & FEAT_HBMHIST) {   // many detectors: the kernel with everything, or the kernels with cells that count in HBM
+        if (sizeof(real) == 8 || !(features & FEAT_CELLS)) return (const void *)trace_kernel<real, FEAT_ALL>;
+        switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+        case 0: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST>;
+        case FEAT_SPECTRA: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST | FEAT_SPECTRA>;
+        case FEAT_BACK: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST | FEAT_BACK>;
+        default: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST | FEAT_SPECTRA | FEAT_BACK>;
+        }
+    }
     if constexpr (sizeof(real) == 8) {
         return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);   // (float64 tables hold no runs)
     } else {
+        if ((features & FEAT_CELLS) && (features & FEAT_RUNS)) {  // cells, with runs in the hit table or tiled faces
+            switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+            case 0: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS>;
+            case FEAT_SPECTRA: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_SPECTRA>;
+            case FEAT_BACK: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_BACK>;
+            default: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_SPECTRA | FEAT_BACK>;
+            }
+        }
         if (features & FEAT_RUNS) {  // runs: the rectangle-only kernels of the world frame, else the one with everything
             if (features & (FEAT_ALIGNED | FEAT_SHAPES | FEAT_FRAMES)) return (const void *)trace_kernel<real, FEAT_ALL>;
             switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
@@ -1981,7 +2095,7 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     const int lds_limit = 160 * 1024;
     for (const void *fn : {trace32, trace64, (const void *)step_tape_kernel<float>, (const void *)photon_op_kernel<float>,
                            (const void *)step_tape_kernel<double>, (const void *)photon_op_kernel<double>,
-                           (const void *)preset_hit_kernel})
+                           (const void *)preset_hit_kernel<false>, (const void *)preset_hit_kernel<true>})
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
     {  // the workgroup size that puts the most waves on a SIMD; the smaller one on a tie
         int best_waves = -1;
@@ -2012,8 +2126,12 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     // kernels with cells, strict point source: the first hit of every photon, found once by the search itself
     if ((s->features() & FEAT_CELLS) && s->img32.src.dir_mode == 0 && !s->has_area && !getenv("RTMC_NO_PRESET")) {
         CellHeader *hdr = (CellHeader *)((char *)p.lds32 + s->img32.lay.cells);
-        hipLaunchKernelGGL(preset_hit_kernel, dim3(1), dim3(64), s->img32.lay.total, p.stream,
-                           (const DevScene<float> *)p.scene32, hdr);
+        if (s->features() & FEAT_RUNS)
+            hipLaunchKernelGGL(preset_hit_kernel<true>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
+                               (const DevScene<float> *)p.scene32, hdr);
+        else
+            hipLaunchKernelGGL(preset_hit_kernel<false>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
+                               (const DevScene<float> *)p.scene32, hdr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(p.stream));
     }

@@ -136,7 +136,7 @@ struct alignas(16) DevCell {
     float c[3];            // centre of the box
     float hw[3];           // half extents plus a margin: farther out a point is not taken to be in the cell
                            // (negative: the record is not usable, every search from it fails)
-    int32_t idlo[3], idhi[3];  // element indices of the low and high faces
+    int32_t idlo[3], idhi[3];  // element indices of the low and high faces; -(g + 2): the face is tiled, see TileGrid g
     uint32_t pad[2];
 };
 static_assert(sizeof(DevCell) == 80, "five 16-byte LDS reads per lane");
@@ -154,6 +154,13 @@ struct alignas(16) CellHeader {
                              // | F_LIST if there is none and the source's cell is no place for a confined search
     int32_t n_cells;
 };
+// A face of a cell that is tiled by several rectangles (DevCell::idlo/idhi < -1 name grid -(id + 2)): the grid
+// of a run of coplanar rectangles (RunHdr) without its plane, gathered per lane.
+struct alignas(16) TileGrid {
+    float gi0, gj0, inv_wi, inv_wj;
+    int32_t ni_1, nj_1, cell_off, mem_off;
+};
+constexpr int32_t CONFINED_NONE = (int32_t)0x80000000;   // confined_hit: no answer from the cell
 
 // One medium.
 template <typename real>
@@ -205,7 +212,7 @@ struct DevSource {
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, cells, acc, hist, total;
+    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, cells, tile_grids, acc, hist, total;
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
@@ -509,6 +516,7 @@ struct Lds {
     const uint32_t *run_cells;              // grids of the runs of coplanar rectangles
     const RunMember<real> *run_members;     // their members
     const CellHeader *cells;                // header, then the DevCell records (record 0 = no cell)
+    const TileGrid *tile_grids;             // grids of the tiled faces of cells
     unsigned long long *acc;
     uint32_t *hist;
 };
@@ -1426,10 +1434,15 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
 //   face (equal distances go to the lower list index: left to the list walk) and the landing point
 //   is in the box, within the margin.
 // Anything else -- a photon in a cell that holds other elements, one that leaked through a seam --
-// gets element -2 and waits for the list walk.  Where the two can differ is what the list walk
+// gets element CONFINED_NONE and waits for the list walk.  Where the two can differ is what the list walk
 // itself leaves to rounding: a landing point within an ulp of a face's edge, and a face *behind*
 // the photon whose line parameter comes out as a rounding residue of the admissible sign.
 // The conditions narrow the execution mask one compare after the other (see consider_pair_f32).
+// TILES: a face may be a tiling (a read-out cut into strips); the rectangle that holds the landing
+// point is then looked up through the face's grid and tried exactly as scan_runs_f32 tries the members
+// of a run: the landing point L + t D against the rectangle's own centre and half extents, list
+// order, the first that contains it.
+template <bool TILES>
 __device__ __forceinline__ void confined_hit(const Lds<float> &lds, const Photon<float> &p, float &dnorm, Nearest<float> &out)
 {
     dnorm = M<float>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
@@ -1468,7 +1481,7 @@ __device__ __forceinline__ void confined_hit(const Lds<float> &lds, const Photon
     for (int k = 0; k < 3; k++) dB[k] = tb * D[k] + dL[k];
     const float ta = tb * p.adm_q;
     const int skip = (p.flags & F_WAS_EL) ? p.last_el : -1;
-    int found = -2;
+    int found = CONFINED_NONE;
     unsigned long long saved;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "v_cmpx_le_f32_e64 vcc, |%[lx]|, %[hx]\n\t"
@@ -1487,6 +1500,36 @@ __device__ __forceinline__ void confined_hit(const Lds<float> &lds, const Photon
                    [hx] "v"(hw[0]), [hy] "v"(hw[1]), [hz] "v"(hw[2]), [ta] "v"(ta), [ab] "v"(ab), [am] "v"(am),
                    [ib] "v"(ib), [skip] "v"(skip)
                  : "vcc");
+    if constexpr (TILES) {
+        const bool tiled = (found < -1) & (found != CONFINED_NONE);
+        if (__ballot(tiled) != 0ull) {
+            // the landing point in the in-plane coordinates of the face: axes k + 1, k + 2 of its normal axis k
+            const bool x = a[0] == ab, y = a[1] == ab;
+            const float Li = x ? L[1] : (y ? L[2] : L[0]), Di = x ? D[1] : (y ? D[2] : D[0]);
+            const float Lj = x ? L[2] : (y ? L[0] : L[1]), Dj = x ? D[2] : (y ? D[0] : D[1]);
+            const float Bi = Li + tb * Di, Bj = Lj + tb * Dj;
+            const TileGrid &g = row(lds.tile_grids, tiled ? -found - 2 : 0);
+            const int ci = __builtin_amdgcn_fmed3f(__builtin_floorf((Bi - g.gi0) * g.inv_wi), 0.0f, (float)g.ni_1);
+            const int cj = __builtin_amdgcn_fmed3f(__builtin_floorf((Bj - g.gj0) * g.inv_wj), 0.0f, (float)g.nj_1);
+            const uint32_t *cell = lds.run_cells + 2 * (g.cell_off + mul24(cj, g.ni_1 + 1) + ci);
+            int holder = CONFINED_NONE;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {   // (the second word is empty in all but crowded cells)
+                uint32_t word = tiled ? cell[half] : 0xFFFFFFFFu;
+                while (__ballot((word & 0xFFu) != 0xFFu) != 0ull) {
+                    const uint32_t slot = word & 0xFFu;
+                    word = (word >> 8) | 0xFF000000u;
+                    if (slot != 0xFFu) {
+                        const RunMember<float> &m = row(lds.run_members, g.mem_off + (int)slot);
+                        const bool ok = (M<float>::abs(Bi - m.ci) <= m.hi) & (M<float>::abs(Bj - m.cj) <= m.hj) & (m.index != skip) &
+                                        (holder == CONFINED_NONE);
+                        holder = ok ? m.index : holder;
+                    }
+                }
+            }
+            found = tiled ? holder : found;
+        }
+    }
     const bool preset = (p.flags & F_PRESET) != 0u;   // launched from a strict source: the renew block left the hit on the photon
     out.t = preset ? p.best_t : tb;
     out.e = preset ? p.last_el : found;
@@ -1957,8 +2000,8 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             // RayTrace.py:124-154) has no geometric meaning that a cell number could follow.
             if (nearest.e < 0) p.flags |= F_CELL_MASK;
         } else {
-            confined_hit(lds, p, dnorm, nearest);
-            if (nearest.e == -2) {
+            confined_hit<(FEATURES & FEAT_RUNS) != 0>(lds, p, dnorm, nearest);
+            if (nearest.e == CONFINED_NONE) {
                 tally.stamp(1);
                 return STEP_WIDE;
             }

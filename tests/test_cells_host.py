@@ -26,11 +26,14 @@ def test_cells_found_per_configuration():
             s.close()
     for job, want in ((configs.nested_job(), (3, 3, True)), (configs.twin_job(), (3, 2, True)), (configs.mirror_box_job(), (2, 2, True)),
                       (configs.near_floor_job(), (2, 0, False)),
-                      (configs.flush_detector_job(10), None), (configs.strip_job(10, strips=14), None)):
+                      (configs.strip_job(10, strips=14), (2, 2, True)),      # edge faces tiled by 14 detectors each
+                      (configs.strip_job(10, strips=30), (2, 2, True)),      # ... by 30: detector histogram in HBM
+                      (configs.stacked_job(10, n_slabs=8), (9, 8, True)),    # runs in the hit table beside the cells
+                      (configs.flush_detector_job(10), None), (configs.tiled_floor_job(10), None)):
         rt, s = _scene(job)
         try:
             c = s.cells()
-            if want is None:   # coplanar overlap (guard distance) / runs of coplanar rectangles: other kernels
+            if want is None:   # coplanar overlaps (guard distance): other kernels
                 assert not c["in_use"], c
             else:
                 assert (c["cells"], c["usable"], c["in_use"]) == want, c

@@ -5,7 +5,9 @@ answer the search of a photon that is inside a closed axis-aligned box, with not
 from the three faces it moves towards; photons elsewhere wait for a pass that walks the list.  The
 answers are the list walk's own (same line parameter, same element) except where the list walk
 itself is decided by rounding -- a landing point within an ulp of an edge -- so the tallies of the
-two differ by a few photons in 1e7, never by more; and float64 (which always walks the list,
+two differ by a few photons in 1e7, never by more (S3, S14, S30: slabs whose edge faces are tiled by
+several detectors, the rectangle under the landing point looked up through a grid; stack8: cells
+beside runs of coplanar rectangles in the hit table); and float64 (which always walks the list,
 photon for photon with the checker elsewhere in this suite) is followed as closely as before."""
 import numpy as np
 import pytest
@@ -31,7 +33,8 @@ def _moved(a, b):
     return (d + 1) // 2
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C9", "C1_open", "nested", "twin", "mirror box"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C9", "C1_open", "nested", "twin", "mirror box",
+                                  "S3", "S14", "S30", "stack8"])
 def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
     """The same photon ids with and without cells (RTMC_NO_CELLS): fates differ for at most a few
     photons in 1e6, every photon is accounted for, and the list walk's stale steps -- photons that slip
@@ -43,6 +46,8 @@ def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
             return _scene(configs.twin_job())
         if name == "mirror box":
             return _scene(configs.mirror_box_job())
+        if name == "S30":      # 126 detectors: the histogram is counted in HBM
+            return _scene(configs.strip_job(10, strips=30))
         rt = H.raytrace_for(name)
         return rt, rt.Scene()
     n = 40000 if name == "C1_open" else 4000000
