@@ -526,6 +526,9 @@ CONFIGS = {
     "S3": (strip_job, dict(strips=3)),
     "S14": (strip_job, dict(strips=14)),
     "stack8": (stacked_job, dict(n_slabs=8)),
+    # the stacked slabs and the segmented read-out turned rigidly out of the world's axes
+    "C4r": (rotated_job, dict(base="C4")),
+    "S14r": (rotated_job, dict(base="strips14")),
 }
 
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -78,6 +79,7 @@ __device__ __forceinline__ Lds<real> stage_lds(SceneArg<real> sc, unsigned char 
     l.run_members = reinterpret_cast<const RunMember<real> *>(smem + sc.lay.run_members);
     l.cells = reinterpret_cast<const CellHeader *>(smem + sc.lay.cells);
     l.tile_grids = reinterpret_cast<const TileGrid *>(smem + sc.lay.tile_grids);
+    l.cell_frames = reinterpret_cast<const float *>(smem + sc.lay.cell_frames);
     l.acc = reinterpret_cast<unsigned long long *>(smem + sc.lay.acc);
     l.hist = reinterpret_cast<uint32_t *>(smem + sc.lay.hist);
     return l;
@@ -344,7 +346,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
 // kernels with cells take it from the header of the cell table instead of walking the element
 // list; this kernel, run once when a scene is uploaded, finds it with that very walk (one wave, all
 // lanes alike) and marks the launch flags if there is a hit.
-template <bool RUNS>
+template <int SEARCH>   // the features of the scene's kernel that the list walk depends on
 __global__ void __launch_bounds__(64)
 preset_hit_kernel(const DevScene<float> *scene, CellHeader *hdr)
 {
@@ -359,7 +361,7 @@ preset_hit_kernel(const DevScene<float> *scene, CellHeader *hdr)
     p.wid = sc.src.wid_fixed;
     init_photon_common(sc, p);
     float dnorm;
-    const Nearest<float> first = nearest_valid_hit<RUNS ? FEAT_RUNS : 0>(hot, lds, p, dnorm);
+    const Nearest<float> first = nearest_valid_hit<SEARCH>(hot, lds, p, dnorm);
     if (threadIdx.x == 0 && first.e >= 0) {
         hdr->preset_t = first.t;
         hdr->preset_e = first.e;
@@ -776,6 +778,7 @@ struct CellPlan {
     struct Tile { double ci, cj, hi, hj; int index; };
     std::vector<std::vector<Tile>> tiles;
     std::vector<int> tile_owner;         // the cell each tiled face belongs to
+    int n_frames_used = 1;               // 1 + the highest frame (FrameSet) some cell lies in
 };
 
 struct PerDevice {
@@ -862,14 +865,16 @@ struct rtmc_scene {
         if (has_area || has_coplanar || seam_source || (hist_in_hbm && !cells_in_use())) return FEAT_ALL;
         return (has_aligned ? FEAT_ALIGNED : 0) | (has_shapes ? FEAT_SHAPES | FEAT_FRAMES : 0) |
                (has_spectra ? FEAT_SPECTRA : 0) | (has_back ? FEAT_BACK : 0) | (has_frames ? FEAT_FRAMES : 0) |
-               ((has_runs || ((has_tiles || hist_in_hbm) && cells_in_use())) ? FEAT_RUNS : 0) |
+               ((has_runs || ((has_tiles || hist_in_hbm || has_frames) && cells_in_use())) ? FEAT_RUNS : 0) |
                (cells_in_use() ? FEAT_CELLS : 0) | (hist_in_hbm ? FEAT_HBMHIST : 0);
     }
-    // the kernels with cells exist for rectangle-only scenes of the world frame; those that also hold the code for
-    // runs of coplanar rectangles, tiled faces and the detector histogram in HBM, for isotropic dyes only
+    // the kernels with cells exist for rectangle-only scenes; those that also hold the code for runs of coplanar
+    // rectangles, tiled faces, turned frames or the detector histogram in HBM, for isotropic dyes only, and not for
+    // turned frames together with the histogram in HBM
     bool cells_in_use() const
     {
-        return has_cells && !has_shapes && !has_frames && !((has_runs || has_tiles || hist_in_hbm) && has_aligned);
+        return has_cells && !has_shapes && !((has_runs || has_tiles || hist_in_hbm || has_frames) && has_aligned) &&
+               !(has_frames && hist_in_hbm);
     }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
@@ -888,17 +893,75 @@ struct rtmc_scene {
 
 namespace {
 
-// Finds the cells of a scene: rectangles of the world frame (normal and in-plane axes exactly along
-// the coordinate axes) that close a box.  A face of the box is one rectangle that spans exactly the
-// box, or several that tile it without gap or overlap (a read-out cut into strips); at least one
-// pair of opposite faces must be whole rectangles.  A cell is usable for the confined search if
-// nothing but its faces comes near its box, or if everything that does belongs to one cell nested in
-// it (see DevCell).  Lenses are no faces (a photon passes them without the refraction that moves it
-// from cell to cell).
-CellPlan find_cells(const rtmc_scene_desc *d)
+// The orthonormal frames of a scene's rectangles.  A rectangle whose normal and in-plane axes are
+// mutually perpendicular unit vectors is axis-aligned in the frame whose axes they are (up to order
+// and sign); the world frame is frame 0 and is matched exactly, further frames within 1e-12, in the
+// order in which the element list first needs them.
+struct FrameSet {
+    struct Place { int frame = -1, kn = -1, k1 = -1, k2 = -1; };   // frame and the rows of it that are normal, e1, e2
+    std::vector<std::array<double, 9>> r;   // per frame its axes as rows, in world coordinates
+    std::vector<Place> place;               // per element; frame -1: tested on its full record
+    double coord(int frame, int axis, const double *x) const
+    {   // frame 0: the coordinate itself, so that an axis-aligned scene is described exactly
+        const double *row = &r[frame][3 * axis];
+        return frame == 0 ? x[axis] : row[0] * x[0] + row[1] * x[1] + row[2] * x[2];
+    }
+};
+
+FrameSet assign_frames(const rtmc_scene_desc *d)
+{
+    FrameSet fs;
+    fs.r.push_back({1, 0, 0, 0, 1, 0, 0, 0, 1});
+    fs.place.resize(d->n_elements);
+    auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    // row of frame f that v is (plus or minus); -1 if none.  Frame 0 wants the exact unit vector.
+    auto row_of = [&](const std::array<double, 9> &f, const double *v, bool exact) {
+        for (int a = 0; a < 3; a++) {
+            const double c = std::fabs(dot3(&f[3 * a], v));
+            double off = 0;
+            for (int j = 0; j < 3; j++) off = std::max(off, std::fabs(std::fabs(v[j]) - std::fabs(f[3 * a + j])));
+            if (exact ? (c == 1.0 && off == 0.0) : (std::fabs(c - 1.0) <= 1e-12 && off <= 1e-12)) return a;
+        }
+        return -1;
+    };
+    for (int i = 0; i < d->n_elements; i++) {
+        const rtmc_element &e = d->elements[i];
+        const bool orthonormal = e.geometry == RTMC_GEOM_RECTANGLE &&
+                                 std::fabs(dot3(e.normal, e.normal) - 1) <= 1e-12 && std::fabs(dot3(e.e1, e.e1) - 1) <= 1e-12 &&
+                                 std::fabs(dot3(e.e2, e.e2) - 1) <= 1e-12 && std::fabs(dot3(e.normal, e.e1)) <= 1e-12 &&
+                                 std::fabs(dot3(e.normal, e.e2)) <= 1e-12 && std::fabs(dot3(e.e1, e.e2)) <= 1e-12;
+        if (!orthonormal) continue;
+        size_t fi = 0;
+        int kn = -1, k1 = -1, k2 = -1;
+        for (; fi < fs.r.size(); fi++) {
+            kn = row_of(fs.r[fi], e.normal, fi == 0);
+            k1 = row_of(fs.r[fi], e.e1, fi == 0);
+            k2 = row_of(fs.r[fi], e.e2, fi == 0);
+            if (kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2) break;
+        }
+        if (fi == fs.r.size() && fs.r.size() < MAX_FRAMES) {
+            fs.r.push_back({e.e1[0], e.e1[1], e.e1[2], e.e2[0], e.e2[1], e.e2[2], e.normal[0], e.normal[1], e.normal[2]});
+            k1 = 0; k2 = 1; kn = 2;
+        }
+        if (fi < fs.r.size()) {
+            fs.place[i].frame = (int)fi; fs.place[i].kn = kn; fs.place[i].k1 = k1; fs.place[i].k2 = k2;
+        }
+    }
+    return fs;
+}
+
+// Finds the cells of a scene: rectangles of one orthonormal frame (FrameSet) that close a box that
+// is axis-aligned in that frame.  A face of the box is one rectangle that spans exactly the box, or
+// several that tile it without gap or overlap (a read-out cut into strips); at least one pair of
+// opposite faces must be whole rectangles.  A cell is usable for the confined search if nothing but
+// its faces comes near its box, or if everything that does belongs to one cell nested in it (see
+// DevCell).  Lenses are no faces (a photon passes them without the refraction that moves it from
+// cell to cell).
+CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
 {
     CellPlan plan;
     const int n_el = d->n_elements;
+    const int n_frames = (int)fs.r.size();
     plan.el_cell.assign(n_el, 0);
     plan.el_outer.assign(n_el, 0);
     DevCell none;
@@ -908,42 +971,35 @@ CellPlan find_cells(const rtmc_scene_desc *d)
     if (getenv("RTMC_NO_CELLS")) return plan;
 
     struct Face { int el, axis; double p, c[3], h[3]; };
-    auto unit_axis = [](const double *v) {   // index of the coordinate axis v is (plus or minus), exactly; else -1
-        int k = -1;
-        for (int a = 0; a < 3; a++) {
-            if (v[a] == 0.0) continue;
-            if (std::fabs(v[a]) != 1.0 || k >= 0) return -1;
-            k = a;
-        }
-        return k;
-    };
-    std::vector<Face> faces[3];
-    std::vector<int> face_slot(n_el, -1);   // position of an element in faces[axis]
+    std::vector<std::vector<Face>> faces(3 * (size_t)n_frames);   // [3 frame + axis]
+    std::vector<int> face_slot(n_el, -1);   // position of an element in its list of faces
     double scale = 1.0;
     for (int i = 0; i < n_el; i++) {
         const rtmc_element &e = d->elements[i];
         for (int a = 0; a < 3; a++) scale = std::max(scale, std::fabs(e.support[a]));
-        if (e.geometry != RTMC_GEOM_RECTANGLE || e.type == RTMC_TYPE_LENS) continue;
-        const int kn = unit_axis(e.normal), k1 = unit_axis(e.e1), k2 = unit_axis(e.e2);
-        if (kn < 0 || k1 < 0 || k2 < 0 || kn == k1 || kn == k2 || k1 == k2) continue;
+        const FrameSet::Place &pl = fs.place[i];
+        if (pl.frame < 0 || e.type == RTMC_TYPE_LENS) continue;
         if (!(e.half1 > 0) || !(e.half2 > 0)) continue;
         Face f;
-        f.el = i; f.axis = kn; f.p = e.support[kn];
-        for (int a = 0; a < 3; a++) { f.c[a] = e.support[a]; f.h[a] = 0; }
-        f.h[k1] = e.half1; f.h[k2] = e.half2;
-        face_slot[i] = (int)faces[kn].size();
-        faces[kn].push_back(f);
+        f.el = i; f.axis = pl.kn;
+        for (int a = 0; a < 3; a++) { f.c[a] = fs.coord(pl.frame, a, e.support); f.h[a] = 0; }
+        f.p = f.c[pl.kn];
+        f.h[pl.k1] = e.half1; f.h[pl.k2] = e.half2;
+        std::vector<Face> &list = faces[3 * (size_t)pl.frame + pl.kn];
+        face_slot[i] = (int)list.size();
+        list.push_back(f);
     }
     const double tol = 1e-9 * scale;
-    struct Box { double lo[3], hi[3]; std::vector<int> face[3][2]; bool dropped = false; int parent = -1; };
+    struct Box { int frame; double lo[3], hi[3]; std::vector<int> face[3][2]; bool dropped = false; int parent = -1; };
     std::vector<Box> boxes;
     auto near = [&](double a, double b) { return std::fabs(a - b) <= tol; };
-    // the rectangles of `axis` at plane `p` that make up the face lo..hi: one that spans it exactly, or several
-    // that lie inside it, do not overlap and add up to its area; empty if there is no such set
-    auto find_face = [&](int axis, double p, const double *lo, const double *hi) {
+    // the rectangles of `axis` of a frame at plane `p` that make up the face lo..hi: one that spans it exactly, or
+    // several that lie inside it, do not overlap and add up to its area; empty if there is no such set
+    auto find_face = [&](int frame, int axis, double p, const double *lo, const double *hi) {
         std::vector<int> inside;
+        const std::vector<Face> &list = faces[3 * (size_t)frame + axis];
         const int i = (axis + 1) % 3, j = (axis + 2) % 3;
-        for (const Face &f : faces[axis]) {
+        for (const Face &f : list) {
             if (!near(f.p, p)) continue;
             if (f.c[i] - f.h[i] < lo[i] - tol || f.c[i] + f.h[i] > hi[i] + tol || f.c[j] - f.h[j] < lo[j] - tol ||
                 f.c[j] + f.h[j] > hi[j] + tol) continue;
@@ -952,10 +1008,10 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         if (inside.empty() || inside.size() > 255) return std::vector<int>();
         double area = 0;
         for (size_t a = 0; a < inside.size(); a++) {
-            const Face &fa = faces[axis][face_slot[inside[a]]];
+            const Face &fa = list[face_slot[inside[a]]];
             area += 4.0 * fa.h[i] * fa.h[j];
             for (size_t b = a + 1; b < inside.size(); b++) {   // interiors must not overlap
-                const Face &fb = faces[axis][face_slot[inside[b]]];
+                const Face &fb = list[face_slot[inside[b]]];
                 if (std::fabs(fa.c[i] - fb.c[i]) < fa.h[i] + fb.h[i] - tol && std::fabs(fa.c[j] - fb.c[j]) < fa.h[j] + fb.h[j] - tol)
                     return std::vector<int>();
             }
@@ -964,35 +1020,38 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         if (std::fabs(area - whole) > 1e-9 * whole) return std::vector<int>();
         return inside;
     };
-    for (int ax = 0; ax < 3; ax++) {
-        const int i = (ax + 1) % 3, j = (ax + 2) % 3;
-        for (const Face &A : faces[ax]) {
-            // the nearest face above A with the same outline closes the box along this axis
-            const Face *B = nullptr;
-            for (const Face &o : faces[ax])
-                if (o.p > A.p + tol && near(o.c[i], A.c[i]) && near(o.c[j], A.c[j]) && near(o.h[i], A.h[i]) && near(o.h[j], A.h[j]) &&
-                    (!B || o.p < B->p)) B = &o;
-            if (!B) continue;
-            Box b;
-            b.lo[ax] = A.p; b.hi[ax] = B->p;
-            b.lo[i] = A.c[i] - A.h[i]; b.hi[i] = A.c[i] + A.h[i];
-            b.lo[j] = A.c[j] - A.h[j]; b.hi[j] = A.c[j] + A.h[j];
-            bool known = false;
-            for (const Box &o : boxes) {
-                bool same = true;
-                for (int k = 0; k < 3; k++) same = same && near(o.lo[k], b.lo[k]) && near(o.hi[k], b.hi[k]);
-                known = known || same;
+    for (int frame = 0; frame < n_frames; frame++)
+        for (int ax = 0; ax < 3; ax++) {
+            const int i = (ax + 1) % 3, j = (ax + 2) % 3;
+            const std::vector<Face> &list = faces[3 * (size_t)frame + ax];
+            for (const Face &A : list) {
+                // the nearest face above A with the same outline closes the box along this axis
+                const Face *B = nullptr;
+                for (const Face &o : list)
+                    if (o.p > A.p + tol && near(o.c[i], A.c[i]) && near(o.c[j], A.c[j]) && near(o.h[i], A.h[i]) && near(o.h[j], A.h[j]) &&
+                        (!B || o.p < B->p)) B = &o;
+                if (!B) continue;
+                Box b;
+                b.frame = frame;
+                b.lo[ax] = A.p; b.hi[ax] = B->p;
+                b.lo[i] = A.c[i] - A.h[i]; b.hi[i] = A.c[i] + A.h[i];
+                b.lo[j] = A.c[j] - A.h[j]; b.hi[j] = A.c[j] + A.h[j];
+                bool known = false;
+                for (const Box &o : boxes) {
+                    bool same = o.frame == frame;
+                    for (int k = 0; k < 3; k++) same = same && near(o.lo[k], b.lo[k]) && near(o.hi[k], b.hi[k]);
+                    known = known || same;
+                }
+                if (known) continue;
+                bool closed = true;
+                for (int a = 0; a < 3 && closed; a++) {
+                    b.face[a][0] = find_face(frame, a, b.lo[a], b.lo, b.hi);
+                    b.face[a][1] = find_face(frame, a, b.hi[a], b.lo, b.hi);
+                    closed = !b.face[a][0].empty() && !b.face[a][1].empty();
+                }
+                if (closed && boxes.size() < 254) boxes.push_back(b);   // (cell numbers 1..254; 255 = unknown)
             }
-            if (known) continue;
-            bool closed = true;
-            for (int a = 0; a < 3 && closed; a++) {
-                b.face[a][0] = find_face(a, b.lo[a], b.lo, b.hi);
-                b.face[a][1] = find_face(a, b.hi[a], b.lo, b.hi);
-                closed = !b.face[a][0].empty() && !b.face[a][1].empty();
-            }
-            if (closed && boxes.size() < 254) boxes.push_back(b);   // (cell numbers 1..254; 255 = unknown)
         }
-    }
     // a rectangle that is (part of) a face of two boxes (two boxes sharing a wall) would have to move a photon
     // between three cells: neither box becomes a cell
     {
@@ -1010,8 +1069,9 @@ CellPlan find_cells(const rtmc_scene_desc *d)
     }
     if (boxes.empty()) return plan;
     auto extent = [](const Box &b) { return std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2])); };
-    // b strictly inside a, by a's margin
+    // b strictly inside a (same frame), by a's margin
     auto inside = [&](const Box &b, const Box &a) {
+        if (a.frame != b.frame) return false;
         const double m = 1e-4 * extent(a);
         for (int k = 0; k < 3; k++)
             if (!(a.lo[k] + m <= b.lo[k] && b.hi[k] + m <= a.hi[k])) return false;
@@ -1028,22 +1088,25 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         for (int a = 0; a < 3; a++)
             for (int side = 0; side < 2; side++)
                 for (int e : boxes[i].face[a][side]) face_of[e] = i;
-    // bounding box of any element
-    auto bounds = [&](const rtmc_element &e, double *lo, double *hi) {
+    // bounding box of any element in the coordinates of a frame
+    auto bounds = [&](const rtmc_element &e, int frame, double *lo, double *hi) {
+        auto along = [&](int a, const double *v) {   // component of a direction along axis a of the frame
+            const double zero[3] = {0, 0, 0};
+            return fs.coord(frame, a, v) - fs.coord(frame, a, zero);
+        };
         for (int a = 0; a < 3; a++) {
-            double r;
-            if (e.geometry == RTMC_GEOM_RECTANGLE) r = std::fabs(e.e1[a]) * e.half1 + std::fabs(e.e2[a]) * e.half2;
-            else if (e.geometry == RTMC_GEOM_CIRCLE) r = e.half1;
-            else if (e.geometry == RTMC_GEOM_TRIANGLE) {
-                lo[a] = std::min(e.e1[a], std::min(e.e2[a], e.vertex3[a]));
-                hi[a] = std::max(e.e1[a], std::max(e.e2[a], e.vertex3[a]));
-                continue;
-            } else {  // cylinder: support and normal are the end points of the axis
-                lo[a] = std::min(e.support[a], e.normal[a]) - e.half1;
-                hi[a] = std::max(e.support[a], e.normal[a]) + e.half1;
-                continue;
+            if (e.geometry == RTMC_GEOM_TRIANGLE) {
+                const double q[3] = {fs.coord(frame, a, e.e1), fs.coord(frame, a, e.e2), fs.coord(frame, a, e.vertex3)};
+                lo[a] = std::min(q[0], std::min(q[1], q[2])); hi[a] = std::max(q[0], std::max(q[1], q[2]));
+            } else if (e.geometry == RTMC_GEOM_CYLINDER) {   // support and normal are the end points of the axis
+                const double q[2] = {fs.coord(frame, a, e.support), fs.coord(frame, a, e.normal)};
+                lo[a] = std::min(q[0], q[1]) - e.half1; hi[a] = std::max(q[0], q[1]) + e.half1;
+            } else {
+                const double r = e.geometry == RTMC_GEOM_CIRCLE ? e.half1
+                                                                : std::fabs(along(a, e.e1)) * e.half1 + std::fabs(along(a, e.e2)) * e.half2;
+                const double c = fs.coord(frame, a, e.support);
+                lo[a] = c - r; hi[a] = c + r;
             }
-            lo[a] = e.support[a] - r; hi[a] = e.support[a] + r;
         }
     };
     plan.cells.resize(2 * (1 + n_box), none);
@@ -1057,7 +1120,7 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         for (int e = 0; e < n_el && !dirty; e++) {
             if (face_of[e] == i) continue;
             double lo[3], hi[3];
-            bounds(d->elements[e], lo, hi);
+            bounds(d->elements[e], b.frame, lo, hi);
             bool apart = false;
             for (int k = 0; k < 3; k++) apart = apart || hi[k] < b.lo[k] - m || lo[k] > b.hi[k] + m;
             if (apart) continue;
@@ -1069,14 +1132,17 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         bool fits = true;
         DevCell c;
         memset(&c, 0, sizeof c);
+        c.frame = b.frame;
+        plan.n_frames_used = std::max(plan.n_frames_used, b.frame + 1);
         for (int k = 0; k < 3; k++) {
             int32_t *ids[2] = {&c.idlo[k], &c.idhi[k]};
             float *plane[2] = {&c.plo[k], &c.phi[k]};
             for (int side = 0; side < 2; side++) {
                 const std::vector<int> &f = b.face[k][side];
-                *plane[side] = (float)d->elements[f[0]].support[k];
+                // (the plane coordinate as the hit table holds it, HitRec::p0)
+                *plane[side] = (float)fs.coord(b.frame, k, d->elements[f[0]].support);
                 for (int e : f)   // (tiles of one plane must share its float32 coordinate, as the hit table's runs do)
-                    if ((float)d->elements[e].support[k] != *plane[side]) fits = false;
+                    if ((float)fs.coord(b.frame, k, d->elements[e].support) != *plane[side]) fits = false;
                 if (f.size() == 1) {
                     *ids[side] = f[0];
                 } else {   // a tiled face: its rectangles as the hit table describes them, looked up through a grid
@@ -1084,7 +1150,7 @@ CellPlan find_cells(const rtmc_scene_desc *d)
                     const int ai = (k + 1) % 3, aj = (k + 2) % 3;
                     std::vector<CellPlan::Tile> list;
                     for (int e : f) {
-                        const Face &fe = faces[k][face_slot[e]];
+                        const Face &fe = faces[3 * (size_t)b.frame + k][face_slot[e]];
                         list.push_back({fe.c[ai], fe.c[aj], fe.h[ai], fe.h[aj], e});
                     }
                     std::sort(list.begin(), list.end(), [](const CellPlan::Tile &x, const CellPlan::Tile &y) { return x.index < y.index; });
@@ -1115,7 +1181,10 @@ CellPlan find_cells(const rtmc_scene_desc *d)
         const Box &b = boxes[i];
         const double m = 1e-4 * extent(b);
         bool in = true;
-        for (int k = 0; k < 3; k++) in = in && b.lo[k] + m < d->source.location[k] && d->source.location[k] < b.hi[k] - m;
+        for (int k = 0; k < 3; k++) {
+            const double x = fs.coord(b.frame, k, d->source.location);
+            in = in && b.lo[k] + m < x && x < b.hi[k] - m;
+        }
         if (in && (start < 0 || volume(b) < volume(boxes[start]))) start = i;
     }
     plan.start_cell = start < 0 ? 0 : 1 + start;
@@ -1129,7 +1198,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<int> &cdf_wid_off, const std::vector<int> &mat_abs_slot,
                  const std::vector<HostTable> &absA, const std::vector<HostTable> &absD, int src_cdf,
                  const std::vector<uint32_t> &energy_fx, const std::vector<uint16_t> &wid_cbin, int n_bins,
-                 const std::vector<int32_t> &el_slot, int n_dump, const CellPlan &plan, DeviceImage<real> &img)
+                 const std::vector<int32_t> &el_slot, int n_dump, const FrameSet &fs, const CellPlan &plan,
+                 DeviceImage<real> &img)
 {
     const int n_el = d->n_elements, n_mat = d->n_materials;
     const int n_wid = (int)wl.size();
@@ -1193,60 +1263,24 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     // in-plane axes are mutually perpendicular joins the frame whose axes they
     // are (up to order and sign); the world frame is frame 0 and is matched exactly.
     struct Frame { double r[3][3]; std::vector<HitRec<real>> group[3]; };
-    std::vector<Frame> frames(1);
-    for (int a = 0; a < 3; a++)
-        for (int c = 0; c < 3; c++) frames[0].r[a][c] = a == c ? 1.0 : 0.0;
+    std::vector<Frame> frames(fs.r.size());
+    for (size_t fi = 0; fi < fs.r.size(); fi++)
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) frames[fi].r[a][c] = fs.r[fi][3 * a + c];
     std::vector<HitRec<real>> general;
-    auto dot3 = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
-    // row of `f` that v is (plus or minus); -1 if none.  Frame 0 wants the exact unit vector.
-    auto row_of = [&](const Frame &f, const double *v, bool exact) {
-        for (int a = 0; a < 3; a++) {
-            const double c = std::fabs(dot3(f.r[a], v));
-            double off = 0;
-            for (int j = 0; j < 3; j++) off = std::max(off, std::fabs(std::fabs(v[j]) - std::fabs(f.r[a][j])));
-            if (exact ? (c == 1.0 && off == 0.0) : (std::fabs(c - 1.0) <= 1e-12 && off <= 1e-12)) return a;
-        }
-        return -1;
-    };
     for (int i = 0; i < n_el; i++) {
         const rtmc_element &e = d->elements[i];
         HitRec<real> h;
         memset(&h, 0, sizeof h);
         h.index = i;
-        bool placed = false;
-        const bool orthonormal = e.geometry == RTMC_GEOM_RECTANGLE &&
-                                 std::fabs(dot3(e.normal, e.normal) - 1) <= 1e-12 && std::fabs(dot3(e.e1, e.e1) - 1) <= 1e-12 &&
-                                 std::fabs(dot3(e.e2, e.e2) - 1) <= 1e-12 && std::fabs(dot3(e.normal, e.e1)) <= 1e-12 &&
-                                 std::fabs(dot3(e.normal, e.e2)) <= 1e-12 && std::fabs(dot3(e.e1, e.e2)) <= 1e-12;
-        if (orthonormal) {
-            size_t fi = 0;
-            int kn = -1, k1 = -1, k2 = -1;
-            for (; fi < frames.size(); fi++) {
-                kn = row_of(frames[fi], e.normal, fi == 0);
-                k1 = row_of(frames[fi], e.e1, fi == 0);
-                k2 = row_of(frames[fi], e.e2, fi == 0);
-                if (kn >= 0 && k1 >= 0 && k2 >= 0 && kn != k1 && kn != k2 && k1 != k2) break;
-            }
-            if (fi == frames.size() && frames.size() < MAX_FRAMES) {
-                Frame f;
-                for (int c = 0; c < 3; c++) { f.r[0][c] = e.e1[c]; f.r[1][c] = e.e2[c]; f.r[2][c] = e.normal[c]; }
-                frames.push_back(f);
-                k1 = 0; k2 = 1; kn = 2;
-            }
-            if (fi < frames.size()) {
-                const Frame &f = frames[fi];
-                const int ai = (kn + 1) % 3, aj = (kn + 2) % 3;
-                // frame 0: the coordinate itself, so that an axis-aligned scene is described exactly
-                auto coord = [&](int a) { return fi == 0 ? e.support[a] : dot3(f.r[a], e.support); };
-                h.p0 = (real)coord(kn);
-                h.ci = (real)coord(ai); h.cj = (real)coord(aj);
-                h.hi = (real)(k1 == ai ? e.half1 : e.half2);
-                h.hj = (real)(k1 == ai ? e.half2 : e.half1);
-                frames[fi].group[kn].push_back(h);
-                placed = true;
-            }
-        }
-        if (!placed) general.push_back(h);
+        const FrameSet::Place &pl = fs.place[i];
+        if (pl.frame < 0) { general.push_back(h); continue; }
+        const int kn = pl.kn, ai = (kn + 1) % 3, aj = (kn + 2) % 3;
+        h.p0 = (real)fs.coord(pl.frame, kn, e.support);
+        h.ci = (real)fs.coord(pl.frame, ai, e.support); h.cj = (real)fs.coord(pl.frame, aj, e.support);
+        h.hi = (real)(pl.k1 == ai ? e.half1 : e.half2);
+        h.hj = (real)(pl.k1 == ai ? e.half2 : e.half1);
+        frames[pl.frame].group[kn].push_back(h);
     }
     auto pad = [](std::vector<HitRec<real>> &recs) {
         while (recs.size() % HIT_CHUNK) {  // padding that no ray can hit
@@ -1540,6 +1574,11 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     lay.run_members = (uint32_t)off; off = align(off + sizeof(RunMember<real>) * run_members.size());
     lay.cells = (uint32_t)off; off = align(off + sizeof(CellHeader) + sizeof(DevCell) * cells.size());
     lay.tile_grids = (uint32_t)off; off = align(off + sizeof(TileGrid) * tile_grids.size());
+    // axes of the frames that hold cells, rows of three in twelve floats (three 16-byte reads per lane)
+    std::vector<float> cell_frames(12 * (size_t)plan.n_frames_used, 0.0f);
+    for (int f = 0; f < plan.n_frames_used; f++)
+        for (int j = 0; j < 9; j++) cell_frames[12 * f + j] = (float)fs.r[f][j];
+    lay.cell_frames = (uint32_t)off; off = align(off + 4 * cell_frames.size());
     lay.acc = (uint32_t)off;
     lay.n_wid = (uint32_t)n_wid;
     lay.n_bins = (uint32_t)n_bins;
@@ -1574,6 +1613,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         memcpy(img.lds.data() + lay.cells, &hdr, sizeof hdr);
         memcpy(img.lds.data() + lay.cells + sizeof hdr, cells.data(), sizeof(DevCell) * cells.size());
         memcpy(img.lds.data() + lay.tile_grids, tile_grids.data(), sizeof(TileGrid) * tile_grids.size());
+        memcpy(img.lds.data() + lay.cell_frames, cell_frames.data(), 4 * cell_frames.size());
     }
 
     const rtmc_source &s = d->source;
@@ -1875,12 +1915,13 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
         for (size_t w = 0; w < wl.size(); w++)
             s->eqeT[(size_t)t * wl.size() + w] = threshold32(q.y[nearest_index(q.x, wl[w])]);
     }
-    const CellPlan plan = find_cells(d);
+    const FrameSet fs = assign_frames(d);
+    const CellPlan plan = find_cells(d, fs);
     s->has_cells = plan.n_usable > 0;
     s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
     s->has_tiles = !plan.tiles.empty();
-    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, plan, s->img32);
-    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, plan, s->img64);
+    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, s->img32);
+    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
     s->has_frames = (s->img32.n_group[3] >> 16) != 0;
     s->has_runs = s->img32.has_runs;
@@ -1959,6 +2000,14 @@ static const void *trace_function(int features)
     if constexpr (sizeof(real) == 8) {
         return trace_variant<real, FEAT_SPECTRA | FEAT_BACK>(features);   // (float64 tables hold no runs)
     } else {
+        if ((features & FEAT_CELLS) && (features & FEAT_FRAMES)) {  // cells in turned frames (with the code for runs and tiled faces)
+            switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+            case 0: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_FRAMES | FEAT_RUNS>;
+            case FEAT_SPECTRA: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_FRAMES | FEAT_RUNS | FEAT_SPECTRA>;
+            case FEAT_BACK: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_FRAMES | FEAT_RUNS | FEAT_BACK>;
+            default: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_FRAMES | FEAT_RUNS | FEAT_SPECTRA | FEAT_BACK>;
+            }
+        }
         if ((features & FEAT_CELLS) && (features & FEAT_RUNS)) {  // cells, with runs in the hit table or tiled faces
             switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
             case 0: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS>;
@@ -2095,7 +2144,8 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     const int lds_limit = 160 * 1024;
     for (const void *fn : {trace32, trace64, (const void *)step_tape_kernel<float>, (const void *)photon_op_kernel<float>,
                            (const void *)step_tape_kernel<double>, (const void *)photon_op_kernel<double>,
-                           (const void *)preset_hit_kernel<false>, (const void *)preset_hit_kernel<true>})
+                           (const void *)preset_hit_kernel<0>, (const void *)preset_hit_kernel<FEAT_RUNS>,
+                           (const void *)preset_hit_kernel<FEAT_RUNS | FEAT_FRAMES>})
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_limit));
     {  // the workgroup size that puts the most waves on a SIMD; the smaller one on a tie
         int best_waves = -1;
@@ -2126,11 +2176,15 @@ static int init_device(rtmc_scene *s, int device, PerDevice &p)
     // kernels with cells, strict point source: the first hit of every photon, found once by the search itself
     if ((s->features() & FEAT_CELLS) && s->img32.src.dir_mode == 0 && !s->has_area && !getenv("RTMC_NO_PRESET")) {
         CellHeader *hdr = (CellHeader *)((char *)p.lds32 + s->img32.lay.cells);
-        if (s->features() & FEAT_RUNS)
-            hipLaunchKernelGGL(preset_hit_kernel<true>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
+        const int search = s->features() & (FEAT_RUNS | FEAT_FRAMES);
+        if (search & FEAT_FRAMES)
+            hipLaunchKernelGGL(preset_hit_kernel<FEAT_RUNS | FEAT_FRAMES>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
+                               (const DevScene<float> *)p.scene32, hdr);
+        else if (search & FEAT_RUNS)
+            hipLaunchKernelGGL(preset_hit_kernel<FEAT_RUNS>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
                                (const DevScene<float> *)p.scene32, hdr);
         else
-            hipLaunchKernelGGL(preset_hit_kernel<false>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
+            hipLaunchKernelGGL(preset_hit_kernel<0>, dim3(1), dim3(64), s->img32.lay.total, p.stream,
                                (const DevScene<float> *)p.scene32, hdr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(p.stream));

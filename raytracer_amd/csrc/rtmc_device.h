@@ -137,7 +137,8 @@ struct alignas(16) DevCell {
     float hw[3];           // half extents plus a margin: farther out a point is not taken to be in the cell
                            // (negative: the record is not usable, every search from it fails)
     int32_t idlo[3], idhi[3];  // element indices of the low and high faces; -(g + 2): the face is tiled, see TileGrid g
-    uint32_t pad[2];
+    int32_t frame;             // the orthonormal frame whose coordinates all of the above are in (0: the world's)
+    uint32_t pad;
 };
 static_assert(sizeof(DevCell) == 80, "five 16-byte LDS reads per lane");
 // Every cell has two records: [2 cell] for a photon that is simply in it, [2 cell + 1] for one whose last operation
@@ -212,7 +213,7 @@ struct DevSource {
 
 // Offsets (in bytes) into the LDS image.
 struct LdsLayout {
-    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, cells, tile_grids, acc, hist, total;
+    uint32_t elems, mats, orient, abs, cdf, guide, fx, bin, run_cells, run_members, cells, tile_grids, cell_frames, acc, hist, total;
     uint32_t n_wid;   // wavelength ids
     uint32_t n_bins;  // distinct 1-nm detector bins the wavelength ids fall into
     uint32_t n_dump;  // detector elements
@@ -517,6 +518,7 @@ struct Lds {
     const RunMember<real> *run_members;     // their members
     const CellHeader *cells;                // header, then the DevCell records (record 0 = no cell)
     const TileGrid *tile_grids;             // grids of the tiled faces of cells
+    const float *cell_frames;               // per frame that holds cells: its axes as rows (9 values in 12)
     unsigned long long *acc;
     uint32_t *hist;
 };
@@ -1442,7 +1444,9 @@ __device__ __forceinline__ Nearest<real> nearest_valid_hit(const HotScene<real> 
 // point is then looked up through the face's grid and tried exactly as scan_runs_f32 tries the members
 // of a run: the landing point L + t D against the rectangle's own centre and half extents, list
 // order, the first that contains it.
-template <bool TILES>
+// FRAMES: a cell may lie in a turned frame; the line is then taken into that frame exactly as the list
+// walk does it (nearest_valid_hit), one rotation per search.
+template <bool TILES, bool FRAMES>
 __device__ __forceinline__ void confined_hit(const Lds<float> &lds, const Photon<float> &p, float &dnorm, Nearest<float> &out)
 {
     dnorm = M<float>::sqrt(p.Dx * p.Dx + p.Dy * p.Dy + p.Dz * p.Dz);
@@ -1458,7 +1462,22 @@ __device__ __forceinline__ void confined_hit(const Lds<float> &lds, const Photon
     const float fl[3] = {q3.x, q3.y, q3.z}, fh[3] = {q3.w, q4.x, q4.y};
     const int idlo[3] = {__float_as_int(fl[0]), __float_as_int(fl[1]), __float_as_int(fl[2])};
     const int idhi[3] = {__float_as_int(fh[0]), __float_as_int(fh[1]), __float_as_int(fh[2])};
-    const float L[3] = {p.Lx, p.Ly, p.Lz}, D[3] = {p.Dx, p.Dy, p.Dz};
+    float L[3] = {p.Lx, p.Ly, p.Lz}, D[3] = {p.Dx, p.Dy, p.Dz};
+    if constexpr (FRAMES) {
+        const int frame = __float_as_int(q4.z);
+        if (__ballot(frame != 0) != 0ull) {
+            const Quad *rows = reinterpret_cast<const Quad *>(&row(reinterpret_cast<const Quad *>(lds.cell_frames), 3 * frame));
+            const Quad r0 = rows[0], r1 = rows[1], r2 = rows[2];
+            const float R[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+            const float Lx = R[0] * p.Lx + R[1] * p.Ly + R[2] * p.Lz, Ly = R[3] * p.Lx + R[4] * p.Ly + R[5] * p.Lz,
+                        Lz = R[6] * p.Lx + R[7] * p.Ly + R[8] * p.Lz;
+            const float Dx = R[0] * p.Dx + R[1] * p.Dy + R[2] * p.Dz, Dy = R[3] * p.Dx + R[4] * p.Dy + R[5] * p.Dz,
+                        Dz = R[6] * p.Dx + R[7] * p.Dy + R[8] * p.Dz;
+            const bool turned = frame != 0;
+            L[0] = turned ? Lx : L[0]; L[1] = turned ? Ly : L[1]; L[2] = turned ? Lz : L[2];
+            D[0] = turned ? Dx : D[0]; D[1] = turned ? Dy : D[1]; D[2] = turned ? Dz : D[2];
+        }
+    }
     float t[3], a[3], dL[3], dB[3];
     int id[3];
 #pragma unroll
@@ -2000,7 +2019,7 @@ __device__ __forceinline__ StepResult photon_step(const HotScene<real> &sc, cons
             // RayTrace.py:124-154) has no geometric meaning that a cell number could follow.
             if (nearest.e < 0) p.flags |= F_CELL_MASK;
         } else {
-            confined_hit<(FEATURES & FEAT_RUNS) != 0>(lds, p, dnorm, nearest);
+            confined_hit<(FEATURES & FEAT_RUNS) != 0, (FEATURES & FEAT_FRAMES) != 0>(lds, p, dnorm, nearest);
             if (nearest.e == CONFINED_NONE) {
                 tally.stamp(1);
                 return STEP_WIDE;

@@ -13,7 +13,7 @@ def _scene(job):
 def test_cells_found_per_configuration():
     expect = {"C1": (2, 2, 2, True), "C2": (2, 2, 2, True), "C3": (2, 2, 2, True), "C4": (4, 3, 4, True),
               "C5": (2, 2, 2, True), "C6": (2, 2, 2, True), "C1_open": (1, 1, 0, True),
-              "C8": None, "C2r": (0, 0, 0, False)}
+              "C8": None, "C2r": (2, 2, 2, True)}       # C2r: the same boxes in a turned frame
     for name, want in expect.items():
         s = H.raytrace_for(name).Scene()
         try:

@@ -7,7 +7,8 @@ answers are the list walk's own (same line parameter, same element) except where
 itself is decided by rounding -- a landing point within an ulp of an edge -- so the tallies of the
 two differ by a few photons in 1e7, never by more (S3, S14, S30: slabs whose edge faces are tiled by
 several detectors, the rectangle under the landing point looked up through a grid; stack8: cells
-beside runs of coplanar rectangles in the hit table); and float64 (which always walks the list,
+beside runs of coplanar rectangles in the hit table; C2r, C4r, S14r: the boxes in a turned frame); and
+float64 (which always walks the list,
 photon for photon with the checker elsewhere in this suite) is followed as closely as before."""
 import numpy as np
 import pytest
@@ -34,7 +35,7 @@ def _moved(a, b):
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C9", "C1_open", "nested", "twin", "mirror box",
-                                  "S3", "S14", "S30", "stack8"])
+                                  "S3", "S14", "S30", "stack8", "C2r", "C4r", "S14r"])
 def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
     """The same photon ids with and without cells (RTMC_NO_CELLS): fates differ for at most a few
     photons in 1e6, every photon is accounted for, and the list walk's stale steps -- photons that slip
