@@ -529,6 +529,8 @@ CONFIGS = {
     # the stacked slabs and the segmented read-out turned rigidly out of the world's axes
     "C4r": (rotated_job, dict(base="C4")),
     "S14r": (rotated_job, dict(base="strips14")),
+    # random slabs in random boxes (seed 0; rotated_job(base="RB", seed=...) turns any of them)
+    "RB": (random_boxes_job, dict(seed=0)),
 }
 
 

@@ -107,14 +107,21 @@ def test_cells_against_checker(oracle_mod):
             s.close()
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(24))
 def test_random_boxes(oracle_mod, monkeypatch, seed):
-    """Random slabs in random boxes (configs.random_boxes_job): the float64 kernels photon for photon with the
+    """Random slabs in random boxes (configs.random_boxes_job; from seed 16 on turned rigidly by a random
+    rotation, so that the boxes lie in a frame of their own): the float64 kernels photon for photon with the
     checker, float32 with cells within a few photons of float64, and of float32 without cells."""
     n = 300000
-    rt, s = _scene(configs.random_boxes_job(seed, 10))
+
+    def job():
+        if seed < 16:
+            return configs.random_boxes_job(seed, 10)
+        rng = np.random.RandomState(500 + seed)
+        return configs.rotated_job(base="RB", seed=seed, axis=rng.normal(size=3), angle=rng.uniform(0.1, 3.0), n_photons=10)
+    rt, s = _scene(job())
     monkeypatch.setenv("RTMC_NO_CELLS", "1")
-    _, without = _scene(configs.random_boxes_job(seed, 10))
+    _, without = _scene(job())
     monkeypatch.delenv("RTMC_NO_CELLS")
     try:
         cpu = oracle_mod.OracleScene.from_raytrace(rt).run_threads(n, seed=100 + seed, threads=8)
@@ -124,7 +131,7 @@ def test_random_boxes(oracle_mod, monkeypatch, seed):
         c = s.cells()
         print("random boxes %d: %d elements, cells %s; moved f64/checker %d, f32/f64 %d, cells/list %d of %d"
               % (seed, s.n_elements, c, _moved(g64, cpu), _moved(g32, g64), _moved(g32, plain), n))
-        assert g32["n_photons"] == n and g32["n_lost"] == 0
+        assert g32["n_photons"] == n and g32["n_lost"] == 0 and c["in_use"]
         assert _moved(g64, cpu) <= 4
         assert _moved(g32, g64) <= 6
         assert _moved(g32, plain) <= 4
