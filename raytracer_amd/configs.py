@@ -425,6 +425,19 @@ def mirror_box_job(n_photons=10):
     return job
 
 
+def tilted_slab_job(n_photons=10, angle=0.2):
+    """The slab of C2 turned about the x axis inside its upright detector box: two closed boxes in two
+    different frames, one inside the other."""
+    job = rotated_job(base="C2", axis=(1.0, 0.0, 0.0), angle=angle, n_photons=n_photons)
+    upright = make_job("C2", n_photons)
+    els = np.array(job["Elements"], dtype=np.float64)
+    els[6:] = np.array(upright["Elements"], dtype=np.float64)[6:]
+    sizes = list(job["ElementSize"])
+    sizes[6:] = upright["ElementSize"][6:]
+    job["Elements"], job["ElementSize"], job["Photon"] = els, sizes, upright["Photon"]
+    return job
+
+
 def random_boxes_job(seed, n_photons=10):
     """Random axis-aligned scene for the closed-box search: one to three dye slabs of random size at random,
     non-overlapping places (stacked with gaps or side by side) inside a detector box that may have mirror
@@ -531,6 +544,7 @@ CONFIGS = {
     "S14r": (rotated_job, dict(base="strips14")),
     # random slabs in random boxes (seed 0; rotated_job(base="RB", seed=...) turns any of them)
     "RB": (random_boxes_job, dict(seed=0)),
+    "tilted": (tilted_slab_job, dict()),
 }
 
 

@@ -1069,12 +1069,20 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
     }
     if (boxes.empty()) return plan;
     auto extent = [](const Box &b) { return std::max(b.hi[0] - b.lo[0], std::max(b.hi[1] - b.lo[1], b.hi[2] - b.lo[2])); };
-    // b strictly inside a (same frame), by a's margin
+    // b strictly inside a, by a's margin; the two may lie in different frames (a turned slab in an upright box): the
+    // corners of b are taken into a's frame
     auto inside = [&](const Box &b, const Box &a) {
-        if (a.frame != b.frame) return false;
         const double m = 1e-4 * extent(a);
-        for (int k = 0; k < 3; k++)
-            if (!(a.lo[k] + m <= b.lo[k] && b.hi[k] + m <= a.hi[k])) return false;
+        for (int corner = 0; corner < 8; corner++) {
+            const double q[3] = {corner & 1 ? b.hi[0] : b.lo[0], corner & 2 ? b.hi[1] : b.lo[1], corner & 4 ? b.hi[2] : b.lo[2]};
+            double world[3] = {0, 0, 0};
+            for (int k = 0; k < 3; k++)
+                for (int c = 0; c < 3; c++) world[c] += q[k] * fs.r[b.frame][3 * k + c];
+            for (int k = 0; k < 3; k++) {
+                const double x = a.frame == b.frame ? q[k] : fs.coord(a.frame, k, world);
+                if (!(a.lo[k] + m <= x && x + m <= a.hi[k])) return false;
+            }
+        }
         return true;
     };
     auto volume = [](const Box &b) { return (b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); };

@@ -26,6 +26,7 @@ def test_cells_found_per_configuration():
             s.close()
     for job, want in ((configs.nested_job(), (3, 3, True)), (configs.twin_job(), (3, 2, True)), (configs.mirror_box_job(), (2, 2, True)),
                       (configs.near_floor_job(), (2, 0, False)),
+                      (configs.tilted_slab_job(), (2, 2, True)),            # a turned slab in an upright box
                       (configs.strip_job(10, strips=14), (2, 2, True)),      # edge faces tiled by 14 detectors each
                       (configs.strip_job(10, strips=30), (2, 2, True)),      # ... by 30: detector histogram in HBM
                       (configs.stacked_job(10, n_slabs=8), (9, 8, True)),    # runs in the hit table beside the cells
