@@ -4,7 +4,8 @@
 set -u
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_${1:-r1}
-ARGS="bench.py --steps 1 --warmup 0 --photons-per-step ${2:-1e8} --no-cpu-baseline --config ${3:-C2}"
+# (--also "": nothing but the one launch of the workload; the counters are summed over the trace kernel's launches)
+ARGS="bench.py --steps 1 --warmup 0 --photons-per-step ${2:-1e8} --no-cpu-baseline --also= --config ${3:-C2}"
 mkdir -p $OUT
 run() {
   name=$1; shift
