@@ -492,8 +492,10 @@ def random_boxes_job(seed, n_photons=10):
         geometry.append(1)
     mats = [copy.deepcopy(AIR_ROW), dye_row("LR"), dye_row("LRO", conc_b=1.0)]
     strict = rng.rand() < 0.5
-    direction = (float(rng.randint(-3, 4)) / 16.0, float(rng.randint(-3, 4)) / 16.0, -1.0) if strict else (0.0, 0.0, -1.0)
-    start = (first[0] + float(rng.randint(-2, 3)) / 16.0, first[1] + float(rng.randint(-2, 3)) / 16.0, first[2] + 0.75)
+    # (a strict beam with no special relation to the boxes: on a grid of sixteenths it would meet edges and corners
+    # exactly, where float32 and float64 part ways whatever the search)
+    direction = (float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2)), -1.0) if strict else (0.0, 0.0, -1.0)
+    start = (first[0] + float(rng.uniform(-0.12, 0.12)), first[1] + float(rng.uniform(-0.12, 0.12)), first[2] + 0.75)
     photon = _photon(n_photons, start, STRICT if strict else ISOTROPIC, FIXED_WL, 460, "air", direction)
     return {"Elements": np.array(els, dtype=np.float64), "ElementProperties": props, "ElementGeometry": geometry,
             "ElementSize": sizes, "Materials": mats, "Photon": photon}

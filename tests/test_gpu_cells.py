@@ -10,6 +10,8 @@ several detectors, the rectangle under the landing point looked up through a gri
 beside runs of coplanar rectangles in the hit table; C2r, C4r, S14r: the boxes in a turned frame; tilted: a
 turned slab in an upright box); and float64 (which always walks the list,
 photon for photon with the checker elsewhere in this suite) is followed as closely as before."""
+import os
+
 import numpy as np
 import pytest
 
@@ -109,15 +111,19 @@ def test_cells_against_checker(oracle_mod):
             s.close()
 
 
-@pytest.mark.parametrize("seed", range(24))
+# RTMC_FUZZ_SCALE=10 runs ten times as many random scenes (a soak, not part of the suite)
+SCALE = int(os.environ.get("RTMC_FUZZ_SCALE", "1"))
+
+
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_random_boxes(oracle_mod, monkeypatch, seed):
-    """Random slabs in random boxes (configs.random_boxes_job; from seed 16 on turned rigidly by a random
+    """Random slabs in random boxes (configs.random_boxes_job; every third one turned rigidly by a random
     rotation, so that the boxes lie in a frame of their own): the float64 kernels photon for photon with the
     checker, float32 with cells within a few photons of float64, and of float32 without cells."""
     n = 300000
 
     def job():
-        if seed < 16:
+        if seed % 3 != 2:
             return configs.random_boxes_job(seed, 10)
         rng = np.random.RandomState(500 + seed)
         return configs.rotated_job(base="RB", seed=seed, axis=rng.normal(size=3), angle=rng.uniform(0.1, 3.0), n_photons=10)
@@ -135,8 +141,12 @@ def test_random_boxes(oracle_mod, monkeypatch, seed):
               % (seed, s.n_elements, c, _moved(g64, cpu), _moved(g32, g64), _moved(g32, plain), n))
         assert g32["n_photons"] == n and g32["n_lost"] == 0 and c["in_use"]
         assert _moved(g64, cpu) <= 4
-        assert _moved(g32, g64) <= 6
-        assert _moved(g32, plain) <= 4
+        # (a slab with mirrors on all four edges keeps a photon for thousands of reflections, a fifth of them up to
+        # the iteration cap: every rounding difference grows into another path there, so the allowance follows the
+        # number of iterations -- 2e-7 of them between float32 and float64, a quarter of that between the two searches)
+        steps = int(g64["n_steps"])
+        assert _moved(g32, g64) <= 6 + int(2e-7 * steps), steps
+        assert _moved(g32, plain) <= 4 + int(5e-8 * steps), steps
     finally:
         s.close()
         without.close()
