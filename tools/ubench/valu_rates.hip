@@ -37,6 +37,10 @@ k(uint32_t *out, uint32_t seed, unsigned long long *clk)
             } else if (OP == 2) {  // the four xors alone (what OP 1 adds to its multiplies)
                 asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0"
                              : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            } else if (OP == 25) {  // v_bitop3_b32 with the parity table and a scalar operand: the three-way xor of a Philox round
+                asm volatile("v_bitop3_b32 %0, %0, %1, s12 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, s12 bitop3:0x96\n"
+                             "v_bitop3_b32 %2, %2, %3, s12 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, s12 bitop3:0x96"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
             } else if (OP == 3) {  // v_mul_lo_u32
                 asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4"
                              : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(0xD2511F53u));
@@ -147,6 +151,7 @@ int main()
     printf("%d CUs, six waves per SIMD, %d instructions per wave\n", n_cu, LOOPS * REP);
     run<0>("v_fma_f32", out, n_cu, clk);
     run<2>("v_xor_b32", out, n_cu, clk);
+    run<25>("v_bitop3_b32 (xor3, sgpr)", out, n_cu, clk);
     run<6>("v_mul_u32_u24", out, n_cu, clk);
     run<3>("v_mul_lo_u32", out, n_cu, clk);
     run<1>("v_mad_u64_u32 + v_xor_b32", out, n_cu, clk);
