@@ -37,6 +37,24 @@ k(uint32_t *out, uint32_t seed, unsigned long long *clk)
             } else if (OP == 2) {  // the four xors alone (what OP 1 adds to its multiplies)
                 asm volatile("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0"
                              : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            } else if (OP == 26 || OP == 27) {  // v_mad_u64_u32 alone, multiplier in a vector (26) or scalar (27) register
+                uint64_t p0, p1, p2, p3;
+                if (OP == 26)
+                    asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %8, 0\n v_mad_u64_u32 %1, s[10:11], %5, %8, 0\n"
+                                 "v_mad_u64_u32 %2, s[10:11], %6, %8, 0\n v_mad_u64_u32 %3, s[10:11], %7, %8, 0"
+                                 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(a), "v"(b), "v"(c), "v"(d), "v"(0xD2511F53u)
+                                 : "s10", "s11");
+                else
+                    asm volatile("v_mad_u64_u32 %0, s[10:11], %4, %8, 0\n v_mad_u64_u32 %1, s[10:11], %5, %8, 0\n"
+                                 "v_mad_u64_u32 %2, s[10:11], %6, %8, 0\n v_mad_u64_u32 %3, s[10:11], %7, %8, 0"
+                                 : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3) : "v"(a), "v"(b), "v"(c), "v"(d), "s"(0xD2511F53u)
+                                 : "s10", "s11");
+                a = (uint32_t)(p0 >> 32); b = (uint32_t)(p1 >> 32); c = (uint32_t)(p2 >> 32); d = (uint32_t)(p3 >> 32);
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            } else if (OP == 28) {  // v_bitop3_b32, three vector operands
+                asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n"
+                             "v_bitop3_b32 %2, %2, %3, %0 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, %1 bitop3:0x96"
+                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
             } else if (OP == 25) {  // v_bitop3_b32 with the parity table and a scalar operand: the three-way xor of a Philox round
                 asm volatile("v_bitop3_b32 %0, %0, %1, s12 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, s12 bitop3:0x96\n"
                              "v_bitop3_b32 %2, %2, %3, s12 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, s12 bitop3:0x96"
@@ -152,6 +170,9 @@ int main()
     run<0>("v_fma_f32", out, n_cu, clk);
     run<2>("v_xor_b32", out, n_cu, clk);
     run<25>("v_bitop3_b32 (xor3, sgpr)", out, n_cu, clk);
+    run<28>("v_bitop3_b32 (xor3, vgprs)", out, n_cu, clk);
+    run<26>("v_mad_u64_u32, vgpr multiplier", out, n_cu, clk);
+    run<27>("v_mad_u64_u32, sgpr multiplier", out, n_cu, clk);
     run<6>("v_mul_u32_u24", out, n_cu, clk);
     run<3>("v_mul_lo_u32", out, n_cu, clk);
     run<1>("v_mad_u64_u32 + v_xor_b32", out, n_cu, clk);
