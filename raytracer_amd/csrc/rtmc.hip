@@ -222,7 +222,7 @@ trace_kernel(const DevScene<real> *scene, DevTallies tl, uint64_t seed, uint64_t
                     const bool donor = outcome == 1;
                     const int off = donor ? m.cdfD_off : m.cdfA_off, len = donor ? m.cdfD_len : m.cdfA_len;
                     const int goff = donor ? m.gD_off : m.gA_off, woff = donor ? m.widD_off : m.widA_off;
-                    p.wid = woff + cdf_pick_guided(lds.cdf + off, len, lds.guide + goff, v_lambda);
+                    p.wid = woff + cdf_pick_guided(lds.cdf + off, len, lds.guide + goff, v_lambda, m.guide_shift);
                     p.status = donor ? RTMC_ST_REEMITTED_DONOR : RTMC_ST_REEMITTED_ACCEPTOR;
                 } else {
                     p.status = RTMC_ST_INTERNAL_CONVERTED;
@@ -860,6 +860,7 @@ struct rtmc_scene {
     bool has_cells = false;         // some rectangles close boxes in which photons can be confined (float32)
     bool has_tiles = false;         // some face of such a box is a tiling of several rectangles
     int n_cells = 0, n_cells_usable = 0, start_cell = 0;
+    int guide_bits = 0;             // bucket bits of the guide tables in the float32 image
     int features() const
     {
         if (has_area || has_coplanar || seam_source || (hist_in_hbm && !cells_in_use())) return FEAT_ALL;
@@ -1207,9 +1208,10 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<HostTable> &absA, const std::vector<HostTable> &absD, int src_cdf,
                  const std::vector<uint32_t> &energy_fx, const std::vector<uint16_t> &wid_cbin, int n_bins,
                  const std::vector<int32_t> &el_slot, int n_dump, const FrameSet &fs, const CellPlan &plan,
-                 DeviceImage<real> &img)
+                 int guide_bits, DeviceImage<real> &img)
 {
     const int n_el = d->n_elements, n_mat = d->n_materials;
+    const int guide_buckets = 1 << guide_bits;
     const int n_wid = (int)wl.size();
     img.elems.resize(n_el);
     for (int i = 0; i < n_el; i++) {
@@ -1515,7 +1517,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         o.cdfD_off = cdf_off[mat_cdfD[i]]; o.cdfD_len = (int)cdfs[mat_cdfD[i]].size();
         o.widD_off = cdf_wid_off[mat_cdfD[i]];
         o.cdfA_off = cdf_off[mat_cdfA[i]]; o.cdfA_len = (int)cdfs[mat_cdfA[i]].size();
-        o.gD_off = mat_cdfD[i] * (GUIDE_BUCKETS + 1); o.gA_off = mat_cdfA[i] * (GUIDE_BUCKETS + 1);
+        o.gD_off = mat_cdfD[i] * (guide_buckets + 1); o.gA_off = mat_cdfA[i] * (guide_buckets + 1);
+        o.guide_shift = 32 - guide_bits;
         o.widA_off = cdf_wid_off[mat_cdfA[i]];
     }
     // aligned acceptors: PhotonObject.py:291-302, MonteCarloFRET.py:124-157
@@ -1553,19 +1556,19 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     for (auto &c : cdfs)
         for (double v : c) cdfT.push_back(threshold32(v));
     if (cdfT.empty()) cdfT.push_back(0xFFFFFFFFu);
-    // guide tables: thresholds below the first value of every bucket of the top GUIDE_BITS bits
+    // guide tables: thresholds below the first value of every bucket of the top guide_bits bits
     std::vector<uint16_t> guide;
     for (auto &c : cdfs) {
         std::vector<uint32_t> T;
         for (double v : c) T.push_back(threshold32(v));
-        for (int b = 0; b <= GUIDE_BUCKETS; b++) {
-            const uint64_t first = (uint64_t)b << (32 - GUIDE_BITS);
-            size_t cnt = 0;
+        size_t cnt = 0;
+        for (int b = 0; b <= guide_buckets; b++) {
+            const uint64_t first = (uint64_t)b << (32 - guide_bits);
             while (cnt < T.size() && (uint64_t)T[cnt] < first) cnt++;
-            guide.push_back((uint16_t)(b == GUIDE_BUCKETS ? T.size() : cnt));
+            guide.push_back((uint16_t)(b == guide_buckets ? T.size() : cnt));
         }
     }
-    if (guide.empty()) guide.assign(GUIDE_BUCKETS + 1, 0);
+    if (guide.empty()) guide.assign(guide_buckets + 1, 0);
 
     auto align = [](size_t v) { return (v + 15) & ~(size_t)15; };
     LdsLayout &lay = img.lay;
@@ -1645,7 +1648,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     o.area[0] = (real)s.area[0]; o.area[1] = (real)s.area[1];
     if (src_cdf >= 0) {
         o.cdf_off = cdf_off[src_cdf]; o.cdf_len = (int)cdfs[src_cdf].size();
-        o.guide_off = src_cdf * (GUIDE_BUCKETS + 1);
+        o.guide_off = src_cdf * (guide_buckets + 1);
+        o.guide_shift = 32 - guide_bits;
     }
 }
 
@@ -1928,8 +1932,40 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     s->has_cells = plan.n_usable > 0;
     s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
     s->has_tiles = !plan.tiles.empty();
-    build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, s->img32);
-    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, s->img64);
+    auto image32 = [&](int guide_bits, DeviceImage<float> &img) {
+        build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx,
+                           s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, guide_bits, img);
+    };
+    // The guide tables of the inverse-CDF picks get as many buckets as the LDS can hold without costing the float32
+    // kernel a wave per SIMD (workgroups of 512, 768 or 1024 threads, RTMC_TRACE_WAVES waves at most) or moving the
+    // detector histogram to HBM: more buckets, fewer steps of bisection (C2 +2 % with 2^12 instead of 2^8).
+    auto waves_per_simd = [](size_t lds_bytes) {
+        int best = 0;
+        for (int block = TRACE_BLOCK; block <= TRACE_BLOCK_MAX; block += 256) {
+            const int resident = (int)(160 * 1024 / (lds_bytes + 1024));   // (a margin for the allocation granule)
+            best = std::max(best, std::min(RTMC_TRACE_WAVES, resident * block / 256));
+        }
+        return best;
+    };
+    image32(GUIDE_BITS_MIN, s->img32);
+    s->guide_bits = GUIDE_BITS_MIN;
+    {
+        const char *forced = getenv("RTMC_GUIDE_BITS");   // experiments
+        for (int bits = GUIDE_BITS_MAX; bits > GUIDE_BITS_MIN; bits -= 2) {
+            if (forced && atoi(forced) != bits) continue;
+            DeviceImage<float> trial;
+            image32(bits, trial);
+            const bool fits = trial.lay.total <= 160 * 1024 && trial.lay.hist_in_hbm == s->img32.lay.hist_in_hbm &&
+                              waves_per_simd(trial.lay.total) >= waves_per_simd(s->img32.lay.total);
+            if (fits || (forced && trial.lay.total <= 160 * 1024)) {
+                s->img32 = std::move(trial);
+                s->guide_bits = bits;
+                break;
+            }
+        }
+        if (forced && atoi(forced) == GUIDE_BITS_MIN) s->guide_bits = GUIDE_BITS_MIN;
+    }
+    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, GUIDE_BITS_MIN, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
     s->has_frames = (s->img32.n_group[3] >> 16) != 0;
     s->has_runs = s->img32.has_runs;
@@ -2289,8 +2325,9 @@ static int launch_and_fold(rtmc_scene *s, PerDevice &p, int device, unsigned lon
     unsigned grid = (unsigned)std::max<uint64_t>(1, std::min(wanted, resident));
 
     if (getenv("RTMC_DEBUG"))
-        fprintf(stderr, "[rtmc] trace launch: %u workgroups of %d threads (%d per CU x %d CUs), %zu B LDS, %llu photons\n",
-                grid, block, per_cu, p.n_cu, lds_bytes, (unsigned long long)n_photons);
+        fprintf(stderr, "[rtmc] trace launch: %u workgroups of %d threads (%d per CU x %d CUs), %zu B LDS (guide tables of 2^%d buckets), "
+                        "%llu photons\n",
+                grid, block, per_cu, p.n_cu, lds_bytes, f32 ? s->guide_bits : GUIDE_BITS_MIN, (unsigned long long)n_photons);
     std::lock_guard<std::mutex> serial(g_gpu[device].launch_mu);
     HIP_TRY(hipMemsetAsync(dev_tallies, 0, 8 * p.tally_words, p.stream));
 #ifdef RTMC_PROFILE_SECTIONS

@@ -176,6 +176,7 @@ struct DevMat {
     int32_t cdfD_off, cdfD_len, widD_off;  // donor emission: threshold table, first wavelength id
     int32_t cdfA_off, cdfA_len, widA_off;  // acceptor emission
     int32_t gD_off, gA_off;                // their guide tables
+    int32_t guide_shift;                   // 32 - the number of leading bits of a variate that name a guide bucket
 };
 
 // Absorption data of one (absorbing medium, wavelength id).
@@ -207,6 +208,7 @@ struct DevSource {
     int32_t dir_mode, wl_mode, start_mat, wid_fixed;
     int32_t cdf_off, cdf_len;  // source spectrum thresholds; wavelength id = row
     int32_t guide_off;         // its guide table
+    int32_t guide_shift;       // 32 - bits per guide bucket number (as DevMat::guide_shift)
     int32_t has_area;          // launch positions spread over a rectangle
     real area[2];              // its full widths along x and y
 };
@@ -511,7 +513,7 @@ struct Lds {
     const DevOrient<real> *orient;
     const DevAbs<real> *abs;
     const uint32_t *cdf;
-    const uint16_t *guide;  // per threshold table GUIDE_BUCKETS + 1 entries: thresholds below bucket b's first value
+    const uint16_t *guide;  // per threshold table 2^bits + 1 entries: thresholds below bucket b's first value
     const uint32_t *fx;    // per wavelength id: llrint(wl_source / wl * 2^24) for a single-line source
     const uint16_t *bin;   // per wavelength id: compact detector bin
     const uint32_t *run_cells;              // grids of the runs of coplanar rectangles
@@ -545,13 +547,14 @@ __device__ __forceinline__ int cdf_pick(const uint32_t *T, int n, uint32_t v)
 }
 
 // The same count found from a guide table: G[b] = number of thresholds below
-// b << (32 - GUIDE_BITS), so the answer lies in [G[b], G[b + 1]] for b = v's top
-// bits and the bisection runs over a handful of entries instead of the table.
-constexpr int GUIDE_BITS = 8;
-constexpr int GUIDE_BUCKETS = 1 << GUIDE_BITS;
-__device__ __forceinline__ int cdf_pick_guided(const uint32_t *T, int n, const uint16_t *G, uint32_t v)
+// b << shift, so the answer lies in [G[b], G[b + 1]] for b = v >> shift and the
+// bisection runs over a handful of entries instead of the table -- over none at all
+// where a bucket holds no threshold.  The host gives the tables as many buckets
+// (2^8, 2^10 or 2^12) as the LDS can hold without costing the kernel a wave per SIMD.
+constexpr int GUIDE_BITS_MIN = 8, GUIDE_BITS_MAX = 12;
+__device__ __forceinline__ int cdf_pick_guided(const uint32_t *T, int n, const uint16_t *G, uint32_t v, int shift)
 {
-    const uint32_t b = v >> (32 - GUIDE_BITS);
+    const uint32_t b = v >> shift;
     int lo = G[b], hi = G[b + 1];
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -903,7 +906,7 @@ __device__ __forceinline__ void renew_photon(SceneArg<real> sc, const HotScene<r
         p.Lx = s.loc[0]; p.Ly = s.loc[1]; p.Lz = s.loc[2];
         p.wid = s.wid_fixed;
         if (SPECTRA && s.wl_mode == 1)
-            p.wid = cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3));
+            p.wid = cdf_pick_guided(lds.cdf + s.cdf_off, s.cdf_len, lds.guide + s.guide_off, g.u32(3), s.guide_shift);
         if (AREA && s.has_area) {  // a block of its own: words 0, 1 = position along x, y
             g.block(0u, BLK_LAUNCH + 1u);
             p.Lx += (g.uniform(0) - real(0.5)) * s.area[0];
