@@ -1,5 +1,7 @@
 """Which closed boxes ("cells") scene creation finds among a scene's rectangles, and which scenes run
 the kernels that use them (host logic of rtmc_scene_create: no GPU needed)."""
+import numpy as np
+
 import helpers as H
 from raytracer_amd import RayTrace, configs
 
@@ -48,5 +50,57 @@ def test_cells_can_be_switched_off(monkeypatch):
     s = H.raytrace_for("C2").Scene()
     try:
         assert s.cells() == {"cells": 0, "usable": 0, "source_cell": 0, "in_use": False, "kernel_features": 0}
+    finally:
+        s.close()
+
+
+def _box(cx, cy, cz, hx, hy, hz, props=None):
+    """Six rectangles that close the box centre +- half extents (as configs._dump_box lays them out)."""
+    els = [[[cx + hx, cy, cz], [1.0, 0.0, 0.0]], [[cx - hx, cy, cz], [-1.0, 0.0, 0.0]],
+           [[cx, cy + hy, cz], [0.0, 1.0, 0.0]], [[cx, cy - hy, cz], [0.0, -1.0, 0.0]],
+           [[cx, cy, cz + hz], [0.0, 0.0, 1.0]], [[cx, cy, cz - hz], [0.0, 0.0, -1.0]]]
+    sizes = [[hy, hz], [hy, hz], [hx, hz], [hx, hz], [hx, hy], [hx, hy]]
+    return els, (props or [[4, 0, 0, ""] for _ in range(6)]), sizes
+
+
+def _job_of(parts):
+    job = configs.make_job("C2", 10)
+    els, props, sizes = [], [], []
+    for e, p, s in parts:
+        els, props, sizes = els + e, props + p, sizes + s
+    job["Elements"] = np.array(els, dtype=np.float64)
+    job["ElementProperties"], job["ElementSize"], job["ElementGeometry"] = props, sizes, [1] * len(els)
+    job["Photon"][1] = [0.0, 0.0, 0.5]
+    return job
+
+
+def test_boxes_that_are_no_cells():
+    """Two boxes that share a wall (one rectangle would be a face of both), two boxes that cut through each
+    other, and a box one face of which is a lens: none of them is a place for a confined search."""
+    glass = lambda: [[2, "air", "LR"] for _ in range(6)]
+    # the right box lacks its own left wall: the left box's right wall closes it
+    left = _box(-1.0, 0.0, 0.0, 1.0, 1.0, 1.0, glass())
+    right = _box(1.0, 0.0, 0.0, 1.0, 1.0, 1.0, glass())
+    right = (right[0][:1] + right[0][2:], right[1][:1] + right[1][2:], right[2][:1] + right[2][2:])
+    outer = _box(0.0, 0.0, 0.0, 4.0, 4.0, 4.0)
+    rt, s = _scene(_job_of([left, right, outer]))
+    try:
+        c = s.cells()
+        assert c["cells"] == 1 and c["usable"] == 0 and not c["in_use"], c      # only the outer box, and it holds loose rectangles
+    finally:
+        s.close()
+    a = _box(-0.5, 0.0, 0.0, 1.0, 1.0, 1.0, glass())
+    b = _box(0.5, 0.25, 0.0, 1.0, 1.0, 1.0, glass())
+    rt, s = _scene(_job_of([a, b, outer]))
+    try:
+        c = s.cells()
+        assert c["cells"] == 3 and c["usable"] == 0 and not c["in_use"], c      # found, but each comes near the other
+    finally:
+        s.close()
+    lens = _box(0.0, 0.0, 0.0, 1.0, 1.0, 1.0, glass())
+    lens[1][4] = [3, 2.0]
+    rt, s = _scene(_job_of([lens, outer]))
+    try:
+        assert not s.cells()["in_use"]                                          # (a lens: the kernels for other shapes)
     finally:
         s.close()
