@@ -386,10 +386,11 @@ int rtmc_scene_info(const rtmc_scene *scene, int32_t info[4]);
 
 /* The closed boxes ("cells") rtmc_scene_create found among the scene's rectangles (no counterpart in
  * the reference, which tries every element on every search, RayTrace.py:128-150; the float32 kernels
- * answer the search of a photon inside such a box from its six faces): info[0] = cells, info[1] = cells
- * in which photons can be confined (nothing but the faces, or one nested cell, inside), info[2] = the
- * cell the source sits in (0 none), info[3] = the feature bits of the scene's float32 trace kernel (bit 9, value
- * 512: the kernels that use the cells). */
+ * answer the search of a photon inside such a box from its six faces): info[0] = cells in its low half,
+ * of which -- high half -- regions (empty parts of a box that holds several others, in front of the faces
+ * of those, which serve as cells too), info[1] = cells in which photons can be confined (nothing but the
+ * faces, or one nested cell, inside; every region), info[2] = the cell the source sits in (0 none), info[3] =
+ * the feature bits of the scene's float32 trace kernel (bit 9, value 512: the kernels that use the cells). */
 int rtmc_scene_cells(const rtmc_scene *scene, int32_t info[4]);
 
 #ifdef __cplusplus

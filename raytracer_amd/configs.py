@@ -425,6 +425,40 @@ def mirror_box_job(n_photons=10):
     return job
 
 
+def glass_pair_job(n_photons=10):
+    """Two dye slabs of the same height and depth side by side in a detector box.  Their edges along x are
+    interfaces like top and bottom (photons leave and enter through them too), those along y detectors (a slab
+    that is glass all around keeps a photon for hundreds of iterations), and the edge of the first that faces
+    the second is read out by six detector strips: the gap between the two is a region that ends on a tiled face."""
+    def box(x0, x1, mat, strips):
+        cx, hx, hy, zc, hz = 0.5 * (x0 + x1), 0.5 * (x1 - x0), 1.5, 0.2, 0.2
+        e = [[[x0, 0.0, zc], [1.0, 0.0, 0.0]], [[0.0, hy, zc], [0.0, -1.0, 0.0]], [[0.0, -hy, zc], [0.0, 1.0, 0.0]],
+             [[cx, 0.0, zc + hz], [0.0, 0.0, 1.0]], [[cx, 0.0, zc - hz], [0.0, 0.0, 1.0]]]
+        for k in (1, 2):
+            e[k][0][0] = cx
+        p = [[2, "air", mat], [4, 0, 0, ""], [4, 0, 0, ""], [2, "air", mat], [2, mat, "air"]]
+        s = [[hy, hz], [hx, hz], [hx, hz], [hx, hy], [hx, hy]]
+        if strips:
+            for k in range(strips):
+                w = hy / strips
+                e.append([[x1, -hy + (2 * k + 1) * w, zc], [-1.0, 0.0, 0.0]])
+                p.append([4, 0, 0, ""])
+                s.append([w, hz])
+        else:
+            e.append([[x1, 0.0, zc], [-1.0, 0.0, 0.0]])
+            p.append([2, mat, "air"])
+            s.append([hy, hz])
+        return e, p, s
+    els, props, sizes = box(-3.0, 0.0, "LR", 6)
+    e, p, s = box(0.3, 2.3, "LRO", 0)
+    els, props, sizes = els + e, props + p, sizes + s
+    e, p, s = _dump_box(0.0, 0.0, 0.2, 4.0, 2.0)
+    els, props, sizes = els + e, props + p, sizes + s
+    return {"Elements": np.array(els, dtype=np.float64), "ElementProperties": props, "ElementGeometry": [1] * len(els),
+            "ElementSize": sizes, "Materials": [copy.deepcopy(AIR_ROW), dye_row("LR"), dye_row("LRO", conc_b=1.0)],
+            "Photon": _photon(n_photons, (1.2, 0.1, 1.0), ISOTROPIC, FIXED_WL, 460, "air", (0.0, 0.0, -1.0))}
+
+
 def tilted_slab_job(n_photons=10, angle=0.2):
     """The slab of C2 turned about the x axis inside its upright detector box: two closed boxes in two
     different frames, one inside the other."""
@@ -441,7 +475,7 @@ def tilted_slab_job(n_photons=10, angle=0.2):
 def random_boxes_job(seed, n_photons=10):
     """Random axis-aligned scene for the closed-box search: one to three dye slabs of random size at random,
     non-overlapping places (stacked with gaps or side by side) inside a detector box that may have mirror
-    walls, random edge types (detector, mirror), sometimes a second box around everything, sometimes a loose
+    walls, random edge types (detector, mirror, interface), sometimes a second box around everything, sometimes a loose
     mirror or detector in the shell; strict or hemispherical source above the first slab."""
     rng = np.random.RandomState(7000 + seed)
     els, props, sizes = [], [], []
@@ -470,8 +504,9 @@ def random_boxes_job(seed, n_photons=10):
              [[cx + hx, cy, zc], [-1.0, 0.0, 0.0]], [[cx - hx, cy, zc], [1.0, 0.0, 0.0]],
              [[cx, cy + hy, zc], [0.0, -1.0, 0.0]], [[cx, cy - hy, zc], [0.0, 1.0, 0.0]]]
         pr = [[2, mat, "air"], [2, "air", mat]]
-        for _ in range(4):
-            pr.append([4, 0, 0, ""] if rng.rand() < 0.6 else [1])
+        for _ in range(4):              # edges: detector, mirror, or glass like top and bottom
+            r = rng.rand()
+            pr.append([4, 0, 0, ""] if r < 0.45 else ([1] if r < 0.7 else [2, mat, "air"]))
         sz = [[hx, hy], [hx, hy], [hy, hw], [hy, hw], [hx, hw], [hx, hw]]
         els, props, sizes = els + e, props + pr, sizes + sz
         if first is None:

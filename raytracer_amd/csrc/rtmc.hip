@@ -770,14 +770,15 @@ struct DeviceImage {
 struct CellPlan {
     std::vector<DevCell> cells;          // two records per cell (see DevCell); cell 0 = "no cell"
     std::vector<uint8_t> el_cell;        // per element: the cell it is a face of (0 none)
-    std::vector<uint8_t> el_outer;       //              and the cell around that one (0 none)
+    std::vector<uint8_t> el_outer;       //              the cell on the outer side of it (0 none)
+    std::vector<uint8_t> el_outward;     //              and whether its normal points out of the cell it is a face of
     int start_cell = 0;                  // innermost cell that holds the source
-    int n_usable = 0;                    // cells in which some photon can be confined (leaf or simple)
+    int n_usable = 0;                    // cells in which some photon can be confined (leaf, simple or region)
+    int n_regions = 0;                   // cells that are regions of a box (the last ones)
     // faces that are tilings: per tiled face its rectangles in list order, in the in-plane coordinates of the hit
     // table (axes k+1, k+2 of normal axis k); DevCell::idlo/idhi name list g as -(g + 2)
     struct Tile { double ci, cj, hi, hj; int index; };
     std::vector<std::vector<Tile>> tiles;
-    std::vector<int> tile_owner;         // the cell each tiled face belongs to
     int n_frames_used = 1;               // 1 + the highest frame (FrameSet) some cell lies in
 };
 
@@ -859,7 +860,7 @@ struct rtmc_scene {
     bool has_runs = false;          // the float32 hit table lists coplanar rectangles as runs
     bool has_cells = false;         // some rectangles close boxes in which photons can be confined (float32)
     bool has_tiles = false;         // some face of such a box is a tiling of several rectangles
-    int n_cells = 0, n_cells_usable = 0, start_cell = 0;
+    int n_cells = 0, n_regions = 0, n_cells_usable = 0, start_cell = 0;   // (n_cells counts the regions too)
     int guide_bits = 0;             // bucket bits of the guide tables in the float32 image
     int features() const
     {
@@ -965,6 +966,7 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
     const int n_frames = (int)fs.r.size();
     plan.el_cell.assign(n_el, 0);
     plan.el_outer.assign(n_el, 0);
+    plan.el_outward.assign(n_el, 0);
     DevCell none;
     memset(&none, 0, sizeof none);
     for (int k = 0; k < 3; k++) none.hw[k] = -1.0f;   // no photon is in it
@@ -1050,7 +1052,7 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
                     b.face[a][1] = find_face(frame, a, b.hi[a], b.lo, b.hi);
                     closed = !b.face[a][0].empty() && !b.face[a][1].empty();
                 }
-                if (closed && boxes.size() < 254) boxes.push_back(b);   // (cell numbers 1..254; 255 = unknown)
+                if (closed && boxes.size() < 127) boxes.push_back(b);   // (the number of a box takes 7 bits of DevElem::info)
             }
         }
     // a rectangle that is (part of) a face of two boxes (two boxes sharing a wall) would have to move a photon
@@ -1119,6 +1121,8 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
         }
     };
     plan.cells.resize(2 * (1 + n_box), none);
+    std::vector<DevCell> box_record(n_box, none);   // the record of each box as a leaf would use it
+    std::vector<char> box_fits(n_box, 0), box_clean(n_box, 0);
     for (int i = 0; i < n_box; i++) {
         const Box &b = boxes[i];
         const double m = 1e-4 * extent(b);
@@ -1164,7 +1168,6 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
                     }
                     std::sort(list.begin(), list.end(), [](const CellPlan::Tile &x, const CellPlan::Tile &y) { return x.index < y.index; });
                     plan.tiles.push_back(list);
-                    plan.tile_owner.push_back(1 + i);
                 }
             }
             c.c[k] = (float)(0.5 * (b.lo[k] + b.hi[k]));
@@ -1177,11 +1180,123 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
         plan.cells[2 * (1 + i)] = leaf ? c : unusable;
         plan.cells[2 * (1 + i) + 1] = (leaf || simple) ? c : unusable;
         if (leaf || simple) plan.n_usable++;
+        box_record[i] = c; box_fits[i] = fits; box_clean[i] = !dirty;
         for (int k = 0; k < 3; k++)
             for (int side = 0; side < 2; side++)
                 for (int e : b.face[k][side]) {
                     plan.el_cell[e] = (uint8_t)(1 + i);
                     plan.el_outer[e] = (uint8_t)(b.parent < 0 ? 0 : 1 + b.parent);
+                    // does the element's normal point out of the box?
+                    const double *axis = &fs.r[b.frame][3 * k], *nrm = d->elements[e].normal;
+                    const double along = axis[0] * nrm[0] + axis[1] * nrm[1] + axis[2] * nrm[2];
+                    plan.el_outward[e] = (side == 1) == (along > 0);
+                }
+    }
+    // A box that holds several others (a stack of slabs in a detector box) confines nobody as a whole, but the
+    // space in front of a face of a nested box K does: the face pushed outwards, through empty space, up to the
+    // first thing it meets -- the wall of the enclosing box P or the facing side of another nested box.  Such a
+    // *region* becomes a cell of its own, named as the cell on the outer side of that face.  Its near side is the
+    // face; its far side is the wall or the face it ends on, if that covers the whole cross-section (otherwise,
+    // like its four other sides, it is open: the search from the cell gives no answer for a photon that leaves
+    // through an open side, CONFINED_NONE, and the list walk takes over).  On the open sides the record's half
+    // extents are drawn in by the margin, so that whether a landing point near the outline of the far face lies
+    // on that rectangle or beside it is left to the list walk's own test of the rectangle.
+    struct Region { int frame, parent; double lo[3], hi[3]; };
+    std::vector<Region> regions;
+    for (int i = 0; i < n_box; i++) {
+        if (!box_fits[i] || !box_clean[i]) continue;
+        const Box &P = boxes[i];
+        std::vector<int> kids;
+        for (int j = 0; j < n_box; j++)
+            if (boxes[j].parent == i) kids.push_back(j);
+        if (kids.size() < 2) continue;
+        const double m = 1e-4 * extent(P);
+        bool regular = true;   // all in P's frame, and clear of each other along some axis
+        for (size_t a = 0; a < kids.size() && regular; a++) {
+            const Box &A = boxes[kids[a]];
+            regular = A.frame == P.frame && box_fits[kids[a]];
+            for (size_t b = a + 1; b < kids.size() && regular; b++) {
+                const Box &B = boxes[kids[b]];
+                bool apart = false;
+                for (int k = 0; k < 3; k++) apart = apart || A.hi[k] + m <= B.lo[k] || B.hi[k] + m <= A.lo[k];
+                regular = apart;
+            }
+        }
+        if (!regular) continue;
+        for (int j : kids)
+            for (int a = 0; a < 3; a++)
+                for (int side = 0; side < 2; side++) {
+                    const Box &K = boxes[j];
+                    const int i1 = (a + 1) % 3, i2 = (a + 2) % 3;
+                    const double p0 = side ? K.hi[a] : K.lo[a];
+                    double q = side ? P.hi[a] : P.lo[a];
+                    int far_box = i, far_side = side;
+                    bool far_whole = true;
+                    for (int o : kids) {
+                        if (o == j) continue;
+                        const Box &O = boxes[o];
+                        // (a box whose outline comes within the margin of K's, seen along the axis, counts as in the way)
+                        if (!(O.lo[i1] < K.hi[i1] + m && O.hi[i1] > K.lo[i1] - m && O.lo[i2] < K.hi[i2] + m && O.hi[i2] > K.lo[i2] - m))
+                            continue;
+                        const double plane = side ? O.lo[a] : O.hi[a];
+                        if (side ? plane < p0 : plane > p0) continue;   // on the other side of K
+                        const bool covers = O.lo[i1] <= K.lo[i1] + tol && O.hi[i1] >= K.hi[i1] - tol && O.lo[i2] <= K.lo[i2] + tol &&
+                                            O.hi[i2] >= K.hi[i2] - tol;
+                        if (near(plane, q)) far_whole = false;   // two boxes end the region in one plane
+                        else if (side ? plane < q : plane > q) { q = plane; far_box = o; far_side = 1 - side; far_whole = covers; }
+                    }
+                    Region r;
+                    r.frame = P.frame; r.parent = i;
+                    for (int k = 0; k < 3; k++) { r.lo[k] = K.lo[k]; r.hi[k] = K.hi[k]; }
+                    r.lo[a] = std::min(p0, q); r.hi[a] = std::max(p0, q);
+                    const DevCell &kr = box_record[j], &fr = box_record[far_box];
+                    DevCell c;
+                    memset(&c, 0, sizeof c);
+                    c.frame = P.frame;
+                    const float near_plane = side ? kr.phi[a] : kr.plo[a], far_plane = far_side ? fr.phi[a] : fr.plo[a];
+                    const int32_t near_id = side ? kr.idhi[a] : kr.idlo[a];
+                    const int32_t far_id = far_whole ? (far_side ? fr.idhi[a] : fr.idlo[a]) : CONFINED_NONE;
+                    c.plo[a] = side ? near_plane : far_plane; c.idlo[a] = side ? near_id : far_id;
+                    c.phi[a] = side ? far_plane : near_plane; c.idhi[a] = side ? far_id : near_id;
+                    const double margin = 1e-5 * extent(P);
+                    c.c[a] = (float)(0.5 * (r.lo[a] + r.hi[a]));
+                    c.hw[a] = (float)(0.5 * (r.hi[a] - r.lo[a]) + margin);
+                    bool usable = c.plo[a] < c.phi[a];
+                    for (int k : {i1, i2}) {
+                        c.plo[k] = (float)K.lo[k]; c.phi[k] = (float)K.hi[k];
+                        c.idlo[k] = c.idhi[k] = CONFINED_NONE;
+                        c.c[k] = (float)(0.5 * (K.lo[k] + K.hi[k]));
+                        c.hw[k] = (float)(0.5 * (K.hi[k] - K.lo[k]) - margin);
+                        usable = usable && c.plo[k] < c.phi[k] && c.hw[k] > 0.0f;
+                    }
+                    if (!usable || !far_whole) continue;   // (open at the far end too: hardly a search would succeed)
+                    // A photon that moves away from the face (F_OUTBOUND) gets a wider record if no nested box reaches
+                    // beyond the plane of the face: all of P on that side of the plane is then empty, its five other
+                    // sides are walls of P, and the side the photon comes from is one it cannot meet.
+                    DevCell out = c;
+                    bool outermost = far_box == i;
+                    for (int o : kids) outermost = outermost && (side ? boxes[o].hi[a] <= p0 + tol : boxes[o].lo[a] >= p0 - tol);
+                    if (outermost) {
+                        out = box_record[i];
+                        (side ? out.plo[a] : out.phi[a]) = near_plane;
+                        (side ? out.idlo[a] : out.idhi[a]) = CONFINED_NONE;
+                        out.c[a] = c.c[a]; out.hw[a] = c.hw[a];
+                    }
+                    int number = -1;
+                    for (size_t g = 0; g < regions.size() && number < 0; g++) {   // (the gap between two boxes, from either side)
+                        bool same = regions[g].frame == r.frame && regions[g].parent == r.parent;
+                        for (int k = 0; k < 3; k++) same = same && near(regions[g].lo[k], r.lo[k]) && near(regions[g].hi[k], r.hi[k]);
+                        if (same) number = 1 + n_box + (int)g;
+                    }
+                    if (number < 0) {
+                        if (1 + n_box + regions.size() >= 254) continue;   // (cell numbers 1..254; 255 = unknown)
+                        number = 1 + n_box + (int)regions.size();
+                        regions.push_back(r);
+                        plan.cells.push_back(c);
+                        plan.cells.push_back(out);
+                        plan.n_usable++;
+                    }
+                    for (int e : K.face[a][side]) plan.el_outer[e] = (uint8_t)number;
                 }
     }
     // the innermost box that holds the source, clear of its faces
@@ -1196,7 +1311,52 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
         }
         if (in && (start < 0 || volume(b) < volume(boxes[start]))) start = i;
     }
+    plan.n_regions = (int)regions.size();
     plan.start_cell = start < 0 ? 0 : 1 + start;
+    for (size_t g = 0; g < regions.size(); g++) {   // ... or a region of that box
+        const Region &r = regions[g];
+        if (r.parent != start) continue;
+        const double m = 1e-4 * extent(boxes[start]);
+        bool in = true;
+        for (int k = 0; k < 3; k++) {
+            const double x = fs.coord(r.frame, k, d->source.location);
+            in = in && r.lo[k] + m < x && x < r.hi[k] - m;
+        }
+        if (!in) continue;
+        // A launched photon that leaves the region through an open side has tried the cell in vain and waits for
+        // the list walk, where all the photons of a renew pass would otherwise have gone together: the region
+        // is the source's cell only if enough of a hemisphere source's photons meet a real side (measured on
+        // random scenes: a gain from about half of them on; a strict source's first hit is known anyway).
+        const DevCell &rec = plan.cells[2 * (1 + n_box + g)];
+        double share = 1.0;
+        if (d->source.direction_mode == 1) {
+            const int nz = 64, nphi = 128;
+            int hits = 0;
+            for (int a = 0; a < nz; a++)
+                for (int b = 0; b < nphi; b++) {
+                    const double z = (a + 0.5) / nz, rho = std::sqrt(1.0 - z * z), phi = 6.283185307179586 * (b + 0.5) / nphi;
+                    const double v[3] = {rho * std::cos(phi), rho * std::sin(phi), z};
+                    double w[3] = {0, 0, 0};   // PhotonObject.py:71-72: the sample times the source's frame
+                    for (int r2 = 0; r2 < 3; r2++)
+                        for (int c = 0; c < 3; c++) w[c] += v[r2] * d->source.frame[3 * r2 + c];
+                    double best = 1e300;
+                    int32_t id = CONFINED_NONE;
+                    for (int k = 0; k < 3; k++) {
+                        const double *axis = &fs.r[r.frame][3 * k];
+                        const double dk = axis[0] * w[0] + axis[1] * w[1] + axis[2] * w[2];
+                        if (dk == 0) continue;
+                        const double x = fs.coord(r.frame, k, d->source.location);
+                        const double t = ((dk > 0 ? (double)rec.phi[k] : (double)rec.plo[k]) - x) / dk;
+                        if (t < best) { best = t; id = dk > 0 ? rec.idhi[k] : rec.idlo[k]; }
+                    }
+                    hits += id != CONFINED_NONE;
+                }
+            share = (double)hits / (nz * nphi);
+        }
+        const char *min_share = getenv("RTMC_REGION_START_MIN");
+        if (getenv("RTMC_DEBUG")) fprintf(stderr, "[rtmc] source in region %d: %.3f of its photons meet a real side\n", 1 + n_box + (int)g, share);
+        if (share >= (min_share ? atof(min_share) : 0.45)) plan.start_cell = 1 + n_box + (int)g;
+    }
     return plan;
 }
 
@@ -1255,7 +1415,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         // (interfaces and mirrors: the cell the element is a face of and the cell around that one in the upper
         // half, read by the kernels with FEAT_CELLS only)
         if (e.type == RTMC_TYPE_INTERFACE || e.type == RTMC_TYPE_MIRROR)
-            o.info = ((int32_t)plan.el_cell[i] << 16) | (int32_t)((uint32_t)plan.el_outer[i] << 24);
+            o.info = ((int32_t)plan.el_cell[i] << 16) | ((int32_t)plan.el_outward[i] << 23) | (int32_t)((uint32_t)plan.el_outer[i] << 24);
         if (e.type == RTMC_TYPE_INTERFACE) o.info |= e.material1 | (e.material2 << 8);
         if (e.type == RTMC_TYPE_DUMP) o.info = ((e.eqe_table + 1) & 0xFF) | (el_slot[i] << 8);
     }
@@ -1443,8 +1603,12 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                 o.ni_1 = r.hdr.ni_1; o.nj_1 = r.hdr.nj_1; o.cell_off = r.hdr.cell_off; o.mem_off = r.hdr.mem_off;
                 img.n_tiled_faces++;
             } else {
-                for (int rec = 0; rec < 2; rec++)
-                    for (int k = 0; k < 3; k++) cells[2 * plan.tile_owner[g] + rec].hw[k] = -1.0f;
+                for (DevCell &c : cells) {   // (the cell of the face, and the regions that end on it)
+                    bool names = false;
+                    for (int k = 0; k < 3; k++) names = names || c.idlo[k] == -((int32_t)g + 2) || c.idhi[k] == -((int32_t)g + 2);
+                    if (names)
+                        for (int k = 0; k < 3; k++) c.hw[k] = -1.0f;
+                }
             }
         }
     }
@@ -1931,6 +2095,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     const CellPlan plan = find_cells(d, fs);
     s->has_cells = plan.n_usable > 0;
     s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
+    s->n_regions = plan.n_regions;
     s->has_tiles = !plan.tiles.empty();
     auto image32 = [&](int guide_bits, DeviceImage<float> &img) {
         build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx,
@@ -2093,7 +2258,7 @@ static const void *trace_function(int features)
 RTMC_API int rtmc_scene_cells(const rtmc_scene *s, int32_t info[4])
 {
     if (!s || !info) return fail(RTMC_EINVAL, "null argument");
-    info[0] = s->n_cells;
+    info[0] = s->n_cells | (s->n_regions << 16);
     info[1] = s->n_cells_usable;
     info[2] = s->start_cell;
     info[3] = s->features();

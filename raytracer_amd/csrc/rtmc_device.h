@@ -45,7 +45,8 @@ struct DevElem {
     real nx, ny, nz, d0;
     int32_t type;   // RTMC_TYPE_* | RTMC_GEOM_* << 8
     int32_t info;   // interface: material1 | material2 << 8; dump: (eqe table + 1) | detector slot << 8;
-                    // interface and mirror: cell the element is a face of << 16 | cell around that one << 24 (DevCell)
+                    // interface and mirror: cell the element is a face of << 16 (7 bits) | its normal points out of
+                    // that cell << 23 | cell on the outer side of the face << 24 (DevCell)
     int32_t nid1;   // interface: name id of material1 (Elements.py:45 compares names)
     int32_t slots;  // interface: (absorption slot of material1 + 1) | (slot of material2 + 1) << 16
     real n1v, n2v;  // interface: refractive indices of material1 / material2
@@ -147,6 +148,16 @@ static_assert(sizeof(DevCell) == 80, "five 16-byte LDS reads per lane");
 //   [2 cell]      nothing but the cell's faces touches its box: every photon in it is confined;
 //   [2 cell + 1]  the same, or the box holds exactly one other cell and nothing else: the photon that moves away
 //                 from that cell cannot meet it again (it is convex) and is confined to the shell around it.
+// A box that holds several cells gets further cells that are no boxes of rectangles but empty *regions* of it: the
+// space in front of a face of a nested cell, up to the wall or the neighbour's face it ends on, with open sides
+// (face index CONFINED_NONE: the search gives no answer for a photon that leaves through one, and half extents drawn
+// in by the margin instead of pushed out, so that what happens at the outline is left to the list walk).  The faces
+// of the nested cell name the region as the cell on their outer side (DevElem::info).  Record [2 region + 1] spans
+// the whole enclosing box beyond the plane of the face where no nested cell reaches that far.  The number a photon
+// carries is a hint that the tests of the search check: wherever it is, a record whose box holds it, and nothing
+// else, gives the answer of the list walk.  (Only a shell -- [2 cell + 1] of a box with a cell in it -- relies on
+// the photon being where its number says and moving as F_OUTBOUND says: both are set by the operation on the
+// nested cell's face, from the geometry of that operation alone.)
 // In front of the cell records: what a launched photon starts with.
 struct alignas(16) CellHeader {
     float preset_t;          // strict source: line parameter and element of the first hit of every photon,
@@ -1951,14 +1962,6 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
                 refract_direction(p, r, -dn, sgn, nx, ny, nz);
                 p.mat = other;
                 p.flags &= ~F_REFLECTED;
-                if constexpr ((FEATURES & FEAT_CELLS) != 0) {
-                    // through a face of cell c (whose enclosing cell is `outer`): out of c, into c, or -- for a
-                    // photon that was in neither -- not known any more
-                    const uint32_t c = ((uint32_t)info >> 16) & 0xFFu, outer = (uint32_t)info >> 24;
-                    const uint32_t cur = (p.flags & F_CELL_MASK) >> F_CELL_SHIFT;
-                    const uint32_t next = c == 0u ? cur : (cur == c ? outer : (cur == outer ? c : CELL_UNKNOWN));
-                    p.flags = (p.flags & ~F_CELL_MASK) | (next << F_CELL_SHIFT);
-                }
                 if (other_slot >= 0)  // PhotonObject.py:283-305, with E as Reflectance left it
                     p.dist = free_path<ALIGNED>(sc, lds, other, other_slot, p, g.expo(1));
                 else
@@ -1978,11 +1981,19 @@ __device__ __forceinline__ bool execute_operation(const HotScene<real> &sc, cons
 #endif
     p.flags |= F_WAS_EL;  // PhotonObject.py:143
     if constexpr ((FEATURES & FEAT_CELLS) != 0) {
-        // The photon now sits on a face of cell c.  If it is in the cell around c -- refracted out of c, or
-        // reflected off it from outside -- it moves away from c and cannot meet it again before it has met
-        // something else: c is convex.
-        const uint32_t c = ((uint32_t)info >> 16) & 0xFFu, outer = (uint32_t)info >> 24;
-        if (c != 0u && ((p.flags & F_CELL_MASK) >> F_CELL_SHIFT) == outer) p.flags |= F_OUTBOUND;
+        // The photon now sits on a face of cell c.  Which side of the face it came from follows from its motion
+        // along the line (sign(t) D, t being negative for a photon that travels backwards along its line after a
+        // reflection) and from whether the element's normal points out of c; a reflection leaves it on that side,
+        // a refraction takes it to the other.  Inside: it is in c.  Outside: it is in the cell the host names for
+        // this side of the face, and it moves away from c, which it cannot meet again before it has met something
+        // else (c is convex).  A re-execution in place (nothing was found) says nothing: the cell stays unknown.
+        const uint32_t c = ((uint32_t)info >> 16) & 0x7Fu, outer = (uint32_t)info >> 24;
+        if (c != 0u && !stale) {
+            const bool normal_outward = (((uint32_t)info >> 23) & 1u) != 0u;
+            const bool from_inside = ((best_t < real(0)) != (dn < real(0))) != normal_outward;
+            const bool inside = from_inside == reflect;
+            p.flags = (p.flags & ~(F_CELL_MASK | F_OUTBOUND)) | ((inside ? c : outer) << F_CELL_SHIFT) | (inside ? 0u : F_OUTBOUND);
+        }
     }
     set_admissibility(p, type, side, nx * p.Dx + ny * p.Dy + nz * p.Dz);
     return false;

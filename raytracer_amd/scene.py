@@ -371,13 +371,14 @@ class Scene:
         return {"runs": out[0], "run_members": out[1], "guard": out[2], "all_features_kernel": bool(out[3])}
 
     def cells(self):
-        """The closed boxes among the scene's rectangles: how many, in how many of them photons can be confined,
+        """The closed boxes among the scene's rectangles, and the empty regions of a box around several others
+        that serve as cells too: how many cells, how many of them regions, in how many photons can be confined,
         the one the source sits in (0 none), whether the scene runs the kernels that use them, and the feature
         bits of its float32 trace kernel (the template argument of `trace_kernel<float, …>`)."""
         out = (C.c_int32 * 4)()
         _abi.check(self.lib.rtmc_scene_cells(self.handle, out), self.lib)
-        return {"cells": out[0], "usable": out[1], "source_cell": out[2], "in_use": bool(out[3] & 512),
-                "kernel_features": int(out[3])}
+        return {"cells": out[0] & 0xFFFF, "regions": out[0] >> 16, "usable": out[1], "source_cell": out[2],
+                "in_use": bool(out[3] & 512), "kernel_features": int(out[3])}
 
     def wavelengths(self):
         cnt = C.c_int64()

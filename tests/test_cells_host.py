@@ -1,5 +1,6 @@
-"""Which closed boxes ("cells") scene creation finds among a scene's rectangles, and which scenes run
-the kernels that use them (host logic of rtmc_scene_create: no GPU needed)."""
+"""Which closed boxes ("cells") scene creation finds among a scene's rectangles, which empty regions of a box
+around several others it adds to them, and which scenes run the kernels that use them (host logic of
+rtmc_scene_create: no GPU needed)."""
 import numpy as np
 
 import helpers as H
@@ -13,7 +14,7 @@ def _scene(job):
 
 
 def test_cells_found_per_configuration():
-    expect = {"C1": (2, 2, 2, True), "C2": (2, 2, 2, True), "C3": (2, 2, 2, True), "C4": (4, 3, 4, True),
+    expect = {"C1": (2, 2, 2, True), "C2": (2, 2, 2, True), "C3": (2, 2, 2, True), "C4": (20, 19, 10, True),   # C4: 4 boxes, 16 regions
               "C5": (2, 2, 2, True), "C6": (2, 2, 2, True), "C1_open": (1, 1, 0, True),
               "C8": None, "C2r": (2, 2, 2, True)}       # C2r: the same boxes in a turned frame
     for name, want in expect.items():
@@ -26,12 +27,12 @@ def test_cells_found_per_configuration():
                 assert (c["cells"], c["usable"], c["source_cell"], c["in_use"]) == want, (name, c)
         finally:
             s.close()
-    for job, want in ((configs.nested_job(), (3, 3, True)), (configs.twin_job(), (3, 2, True)), (configs.mirror_box_job(), (2, 2, True)),
+    for job, want in ((configs.nested_job(), (3, 3, True)), (configs.twin_job(), (14, 13, True)), (configs.mirror_box_job(), (2, 2, True)),
                       (configs.near_floor_job(), (2, 0, False)),
                       (configs.tilted_slab_job(), (2, 2, True)),            # a turned slab in an upright box
                       (configs.strip_job(10, strips=14), (2, 2, True)),      # edge faces tiled by 14 detectors each
                       (configs.strip_job(10, strips=30), (2, 2, True)),      # ... by 30: detector histogram in HBM
-                      (configs.stacked_job(10, n_slabs=8), (9, 8, True)),    # runs in the hit table beside the cells
+                      (configs.stacked_job(10, n_slabs=8), (50, 49, True)),  # runs in the hit table beside the cells
                       (configs.flush_detector_job(10), None), (configs.tiled_floor_job(10), None)):
         rt, s = _scene(job)
         try:
@@ -49,7 +50,33 @@ def test_cells_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("RTMC_NO_CELLS", "1")
     s = H.raytrace_for("C2").Scene()
     try:
-        assert s.cells() == {"cells": 0, "usable": 0, "source_cell": 0, "in_use": False, "kernel_features": 0}
+        assert s.cells() == {"cells": 0, "regions": 0, "usable": 0, "source_cell": 0, "in_use": False, "kernel_features": 0}
+    finally:
+        s.close()
+
+
+def test_regions_of_a_box_that_holds_several():
+    """Three stacked slabs in a detector box: the space in front of each of the 18 slab faces up to what it ends on
+    -- the two gaps are found from either side -- and the hemisphere source starts in the region above the top slab,
+    unless it sits where most of its photons would leave that region through an open side.  Two slabs side by
+    side: twelve faces, the gap between the two found from either side."""
+    rt, s = _scene(configs.stacked_job(10))
+    try:
+        c = s.cells()
+        assert (c["cells"], c["regions"], c["usable"]) == (20, 16, 19) and c["source_cell"] > 4, c
+    finally:
+        s.close()
+    job = configs.stacked_job(10)
+    job["Photon"][1] = [2.3, 2.3, 2.4]          # above a corner of the top slab
+    rt, s = _scene(job)
+    try:
+        c = s.cells()
+        assert c["regions"] == 16 and c["source_cell"] == 4, c      # the detector box itself
+    finally:
+        s.close()
+    rt, s = _scene(configs.twin_job())
+    try:
+        assert s.cells()["regions"] == 11, s.cells()                 # (one region less than faces)
     finally:
         s.close()
 
