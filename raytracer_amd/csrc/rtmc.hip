@@ -959,7 +959,7 @@ FrameSet assign_frames(const rtmc_scene_desc *d)
 // its faces comes near its box, or if everything that does belongs to one cell nested in it (see
 // DevCell).  Lenses are no faces (a photon passes them without the refraction that moves it from
 // cell to cell).
-CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
+CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs, bool with_regions)
 {
     CellPlan plan;
     const int n_el = d->n_elements;
@@ -1204,7 +1204,7 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs)
     struct Region { int frame, parent; double lo[3], hi[3]; };
     std::vector<Region> regions;
     for (int i = 0; i < n_box; i++) {
-        if (!box_fits[i] || !box_clean[i]) continue;
+        if (!with_regions || !box_fits[i] || !box_clean[i]) continue;
         const Box &P = boxes[i];
         std::vector<int> kids;
         for (int j = 0; j < n_box; j++)
@@ -1584,6 +1584,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     // tiled faces of cells: each gets the grid of a run (float32 image only); a tiling the grid cannot hold
     // (more than RUN_CELL_SLOTS rectangles crowd one grid cell) makes its cell unusable
     std::vector<DevCell> cells = plan.cells;
+    if (sizeof(real) != 4) cells.resize(2);   // (the float64 kernels walk the list: "no cell" only)
     std::vector<TileGrid> tile_grids(std::max<size_t>(1, plan.tiles.size()));
     memset(tile_grids.data(), 0, sizeof(TileGrid) * tile_grids.size());
     img.n_tiled_faces = 0;
@@ -1783,7 +1784,8 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
         memset(&hdr, 0, sizeof hdr);
         hdr.preset_e = -1;
         // (F_PRESET is set on the device, see preset_hit_kernel, which then drops F_LIST)
-        hdr.launch_flags = ((uint32_t)plan.start_cell << F_CELL_SHIFT) | (cells[2 * plan.start_cell].hw[0] < 0.0f ? F_LIST : 0u);
+        const size_t start_cell = 2 * (size_t)plan.start_cell < cells.size() ? (size_t)plan.start_cell : 0;
+        hdr.launch_flags = ((uint32_t)start_cell << F_CELL_SHIFT) | (cells[2 * start_cell].hw[0] < 0.0f ? F_LIST : 0u);
         hdr.n_cells = (int32_t)cells.size() / 2 - 1;
         memcpy(img.lds.data() + lay.cells, &hdr, sizeof hdr);
         memcpy(img.lds.data() + lay.cells + sizeof hdr, cells.data(), sizeof(DevCell) * cells.size());
@@ -2092,11 +2094,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
             s->eqeT[(size_t)t * wl.size() + w] = threshold32(q.y[nearest_index(q.x, wl[w])]);
     }
     const FrameSet fs = assign_frames(d);
-    const CellPlan plan = find_cells(d, fs);
-    s->has_cells = plan.n_usable > 0;
-    s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
-    s->n_regions = plan.n_regions;
-    s->has_tiles = !plan.tiles.empty();
+    CellPlan plan = find_cells(d, fs, true);
     auto image32 = [&](int guide_bits, DeviceImage<float> &img) {
         build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx,
                            s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, guide_bits, img);
@@ -2113,6 +2111,27 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
         return best;
     };
     image32(GUIDE_BITS_MIN, s->img32);
+    if (plan.n_regions > 0) {
+        // the regions of a scene with many boxes (two records each): not at the price of a wave per SIMD, of the
+        // detector histogram's place in the LDS, or of the scene's fitting at all
+        const DeviceImage<float> with = s->img32;
+        plan = find_cells(d, fs, false);
+        image32(GUIDE_BITS_MIN, s->img32);
+        const bool affordable = with.lay.total <= 160 * 1024 && with.lay.hist_in_hbm == s->img32.lay.hist_in_hbm &&
+                                waves_per_simd(with.lay.total) >= waves_per_simd(s->img32.lay.total);
+        if (getenv("RTMC_DEBUG"))
+            fprintf(stderr, "[rtmc] regions: LDS image %u bytes with them (%d waves per SIMD, histogram in %s), %u without (%d, %s): %s\n",
+                    with.lay.total, waves_per_simd(with.lay.total), with.lay.hist_in_hbm ? "HBM" : "LDS", s->img32.lay.total,
+                    waves_per_simd(s->img32.lay.total), s->img32.lay.hist_in_hbm ? "HBM" : "LDS", affordable ? "kept" : "dropped");
+        if (affordable) {
+            plan = find_cells(d, fs, true);
+            s->img32 = with;
+        }
+    }
+    s->has_cells = plan.n_usable > 0;
+    s->n_cells = (int)plan.cells.size() / 2 - 1; s->n_cells_usable = plan.n_usable; s->start_cell = plan.start_cell;
+    s->n_regions = plan.n_regions;
+    s->has_tiles = !plan.tiles.empty();
     s->guide_bits = GUIDE_BITS_MIN;
     {
         const char *forced = getenv("RTMC_GUIDE_BITS");   // experiments

@@ -79,6 +79,15 @@ def test_regions_of_a_box_that_holds_several():
         assert s.cells()["regions"] == 11, s.cells()                 # (one region less than faces)
     finally:
         s.close()
+    # 16 stacked slabs: 96 faces, 15 gaps found twice.  41 slabs: the records of the regions would push the detector
+    # histogram out of the LDS, so the scene keeps its 42 boxes only
+    for n_slabs, want in ((16, (98, 81)), (41, (42, 0))):
+        rt, s = _scene(configs.stacked_job(10, n_slabs=n_slabs))
+        try:
+            c = s.cells()
+            assert (c["cells"], c["regions"]) == want and c["in_use"], c
+        finally:
+            s.close()
 
 
 def _box(cx, cy, cz, hx, hy, hz, props=None):

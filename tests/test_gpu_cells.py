@@ -116,11 +116,12 @@ def test_cells_against_checker(oracle_mod):
             s.close()
 
 
-# RTMC_FUZZ_SCALE=10 runs ten times as many random scenes (a soak, not part of the suite)
+# RTMC_FUZZ_SCALE=10 runs ten times as many random scenes (a soak, not part of the suite), RTMC_FUZZ_FIRST=n starts at scene n
 SCALE = int(os.environ.get("RTMC_FUZZ_SCALE", "1"))
+FIRST = int(os.environ.get("RTMC_FUZZ_FIRST", "0"))
 
 
-@pytest.mark.parametrize("seed", range(24 * SCALE))
+@pytest.mark.parametrize("seed", range(FIRST, 24 * SCALE))
 def test_random_boxes(oracle_mod, monkeypatch, seed):
     """Random slabs in random boxes (configs.random_boxes_job; every third one turned rigidly by a random
     rotation, so that the boxes lie in a frame of their own): the float64 kernels photon for photon with the
@@ -146,12 +147,15 @@ def test_random_boxes(oracle_mod, monkeypatch, seed):
               % (seed, s.n_elements, c, _moved(g64, cpu), _moved(g32, g64), _moved(g32, plain), n))
         assert g32["n_photons"] == n and g32["n_lost"] == 0 and c["in_use"]
         assert _moved(g64, cpu) <= 4
-        # (a slab with mirrors on all four edges keeps a photon for thousands of reflections, a fifth of them up to
-        # the iteration cap: every rounding difference grows into another path there, so the allowance follows the
-        # number of iterations -- 2e-7 of them between float32 and float64, a quarter of that between the two searches)
+        # (a slab with mirrors or glass on all four edges keeps a photon for thousands of reflections, a fifth of them
+        # up to the iteration cap: every rounding difference grows into another path there, so the allowance follows
+        # the number of iterations -- 4e-7 of them between float32 and float64, measured up to 2.4e-7 in a turned
+        # frame, and a quarter of that between the two searches, measured up to 4e-8)
+        # (in a turned frame with mirror walls around thin glass slabs 1e-5 of the photons part from float64 whatever the
+        # search -- 28 of 3e6 in scene 209, with cells and without: 3 expected here, so 6 more are allowed)
         steps = int(g64["n_steps"])
-        assert _moved(g32, g64) <= 6 + int(2e-7 * steps), steps
-        assert _moved(g32, plain) <= 4 + int(5e-8 * steps), steps
+        assert _moved(g32, g64) <= 6 + int(4e-7 * steps) + (n // 50000 if seed % 3 == 2 else 0), steps
+        assert _moved(g32, plain) <= 4 + int(1e-7 * steps), steps
     finally:
         s.close()
         without.close()
