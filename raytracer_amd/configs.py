@@ -459,6 +459,29 @@ def glass_pair_job(n_photons=10):
             "Photon": _photon(n_photons, (1.2, 0.1, 1.0), ISOTROPIC, FIXED_WL, 460, "air", (0.0, 0.0, -1.0))}
 
 
+def nested_pair_job(n_photons=10):
+    """Three levels of boxes: two Lumogen Red slabs side by side in a detector box, each with a smaller
+    co-doped slab embedded in it.  Between the slabs: regions of the detector box; inside each slab: the shell
+    around the one box it holds; the edges along y of the outer slabs are detectors, every other face an interface."""
+    def box(x0, x1, hy, z0, z1, inner, outer, y_detectors):
+        cx, hx, zc, hz = 0.5 * (x0 + x1), 0.5 * (x1 - x0), 0.5 * (z0 + z1), 0.5 * (z1 - z0)
+        e = [[[x0, 0.0, zc], [1.0, 0.0, 0.0]], [[x1, 0.0, zc], [-1.0, 0.0, 0.0]],
+             [[cx, hy, zc], [0.0, -1.0, 0.0]], [[cx, -hy, zc], [0.0, 1.0, 0.0]],
+             [[cx, 0.0, z1], [0.0, 0.0, 1.0]], [[cx, 0.0, z0], [0.0, 0.0, 1.0]]]
+        glass = [2, inner, outer]
+        p = [list(glass), list(glass)] + [[4, 0, 0, ""] if y_detectors else list(glass) for _ in range(2)] + [[2, outer, inner], list(glass)]
+        return e, p, [[hy, hz], [hy, hz], [hx, hz], [hx, hz], [hx, hy], [hx, hy]]
+    els, props, sizes = [], [], []
+    for x0, x1, i0, i1 in ((-3.0, -0.2, -2.5, -0.8), (0.2, 3.0, 0.7, 2.5)):
+        for part in (box(x0, x1, 1.5, 0.0, 0.6, "LR", "air", True), box(i0, i1, 1.0, 0.15, 0.45, "LRO", "LR", False)):
+            els, props, sizes = els + part[0], props + part[1], sizes + part[2]
+    e, p, s = _dump_box(0.0, 0.0, 0.5, 4.0, 2.0)
+    els, props, sizes = els + e, props + p, sizes + s
+    return {"Elements": np.array(els, dtype=np.float64), "ElementProperties": props, "ElementGeometry": [1] * len(els),
+            "ElementSize": sizes, "Materials": [copy.deepcopy(AIR_ROW), dye_row("LR"), dye_row("LRO", conc_b=1.0)],
+            "Photon": _photon(n_photons, (-1.5, 0.2, 1.6), ISOTROPIC, FIXED_WL, 460, "air", (0.0, 0.0, -1.0))}
+
+
 def tilted_slab_job(n_photons=10, angle=0.2):
     """The slab of C2 turned about the x axis inside its upright detector box: two closed boxes in two
     different frames, one inside the other."""

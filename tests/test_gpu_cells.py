@@ -10,7 +10,7 @@ several detectors, the rectangle under the landing point looked up through a gri
 beside runs of coplanar rectangles in the hit table; C2r, C4r, S14r: the boxes in a turned frame; tilted: a
 turned slab in an upright box; C4, stack8, twin, glass pair: several boxes in one, with the regions in front of
 their faces as further cells -- glass pair: photons pass through the edges too, and one region ends on a face tiled
-by detectors); and float64 (which always walks the list,
+by detectors; nested pair: boxes in boxes in a box); and float64 (which always walks the list,
 photon for photon with the checker elsewhere in this suite) is followed as closely as before."""
 import os
 
@@ -39,7 +39,7 @@ def _moved(a, b):
 
 
 @pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5", "C6", "C7", "C9", "C1_open", "nested", "twin", "mirror box",
-                                  "S3", "S14", "S30", "stack8", "C2r", "C4r", "S14r", "tilted", "glass pair"])
+                                  "S3", "S14", "S30", "stack8", "C2r", "C4r", "S14r", "tilted", "glass pair", "nested pair"])
 def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
     """The same photon ids with and without cells (RTMC_NO_CELLS): fates differ for at most a few
     photons in 1e6, every photon is accounted for, and the list walk's stale steps -- photons that slip
@@ -53,6 +53,8 @@ def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
             return _scene(configs.mirror_box_job())
         if name == "glass pair":
             return _scene(configs.glass_pair_job())
+        if name == "nested pair":
+            return _scene(configs.nested_pair_job())
         if name == "S30":      # 126 detectors: the histogram is counted in HBM
             return _scene(configs.strip_job(10, strips=30))
         rt = H.raytrace_for(name)
@@ -80,13 +82,14 @@ def test_cells_change_no_tally_but_at_seams(monkeypatch, name):
         without.close()
 
 
-@pytest.mark.parametrize("name", ["nested", "twin", "mirror box", "tilted", "S14", "glass pair", "C4"])
+@pytest.mark.parametrize("name", ["nested", "twin", "mirror box", "tilted", "S14", "glass pair", "nested pair", "C4"])
 def test_cells_follow_float64_photon_for_photon(name):
     """Scenes with nested and neighbouring boxes and with mirror walls: the float32 kernels (cells) against the
     float64 ones (list walk) on the same photons, as closely as the plain slab configurations are."""
     rt, s = _scene({"nested": configs.nested_job, "twin": configs.twin_job, "mirror box": configs.mirror_box_job,
                     "tilted": configs.tilted_slab_job, "S14": lambda: configs.make_job("S14", 10),
-                    "glass pair": configs.glass_pair_job, "C4": lambda: configs.make_job("C4", 10)}[name]())
+                    "glass pair": configs.glass_pair_job, "nested pair": configs.nested_pair_job,
+                    "C4": lambda: configs.make_job("C4", 10)}[name]())
     try:
         n = 2000000
         a = s.run(n, seed=5, precision=_abi.F32)
@@ -103,7 +106,7 @@ def test_cells_against_checker(oracle_mod):
     """The nested, the twin and the mirror-box scene against the CPU checker: float64 photon for photon, float32 within
     a few photons."""
     for make in (configs.nested_job, configs.twin_job, configs.mirror_box_job, configs.tilted_slab_job,
-                 lambda: configs.make_job("S14", 10), configs.glass_pair_job):
+                 lambda: configs.make_job("S14", 10), configs.glass_pair_job, configs.nested_pair_job):
         rt, s = _scene(make())
         try:
             n = 200000
