@@ -871,12 +871,10 @@ struct rtmc_scene {
                (cells_in_use() ? FEAT_CELLS : 0) | (hist_in_hbm ? FEAT_HBMHIST : 0);
     }
     // the kernels with cells exist for rectangle-only scenes; those that also hold the code for runs of coplanar
-    // rectangles, tiled faces, turned frames or the detector histogram in HBM, for isotropic dyes only, and not for
-    // turned frames together with the histogram in HBM
+    // rectangles, tiled faces, turned frames or the detector histogram in HBM, for isotropic dyes only
     bool cells_in_use() const
     {
-        return has_cells && !has_shapes && !((has_runs || has_tiles || hist_in_hbm || has_frames) && has_aligned) &&
-               !(has_frames && hist_in_hbm);
+        return has_cells && !has_shapes && !((has_runs || has_tiles || hist_in_hbm || has_frames) && has_aligned);
     }
     std::vector<rtmc_element> elements;
     std::vector<double> wl;         // wavelength of each id
@@ -1360,6 +1358,18 @@ CellPlan find_cells(const rtmc_scene_desc *d, const FrameSet &fs, bool with_regi
     return plan;
 }
 
+// Waves per SIMD the float32 trace kernel can keep resident beside an LDS image of this size: workgroups of 512,
+// 768 or 1024 threads, RTMC_TRACE_WAVES waves at most.
+int trace_waves_per_simd(size_t lds_bytes)
+{
+    int best = 0;
+    for (int block = TRACE_BLOCK; block <= TRACE_BLOCK_MAX; block += 256) {
+        const int resident = (int)(160 * 1024 / (lds_bytes + 1024));   // (a margin for the allocation granule)
+        best = std::max(best, std::min(RTMC_TRACE_WAVES, resident * block / 256));
+    }
+    return best;
+}
+
 template <typename real>
 void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<std::vector<double>> &cdfs, const std::vector<int> &cdf_off,
@@ -1368,7 +1378,7 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
                  const std::vector<HostTable> &absA, const std::vector<HostTable> &absD, int src_cdf,
                  const std::vector<uint32_t> &energy_fx, const std::vector<uint16_t> &wid_cbin, int n_bins,
                  const std::vector<int32_t> &el_slot, int n_dump, const FrameSet &fs, const CellPlan &plan,
-                 int guide_bits, DeviceImage<real> &img)
+                 int guide_bits, bool hist_may_move, DeviceImage<real> &img)
 {
     const int n_el = d->n_elements, n_mat = d->n_materials;
     const int guide_buckets = 1 << guide_bits;
@@ -1767,6 +1777,11 @@ void build_image(const rtmc_scene_desc *d, const std::vector<double> &wl,
     if (const char *e = getenv("RTMC_LDS_HIST_LIMIT")) hist_limit = (size_t)strtoull(e, nullptr, 10);  // experiments
     const size_t with_hist = align(lay.hist + 4 * (size_t)std::max(1, n_dump * n_bins));
     lay.hist_in_hbm = with_hist > hist_limit ? 1u : 0u;
+    // ... or while it does not cost the float32 kernel a wave per SIMD, in scenes whose kernel counts in HBM at no other
+    // price (`hist_may_move`: the kernels with closed boxes; a read-out of 62 detectors +19 %, eight stacked slabs +13 %)
+    if (sizeof(real) == 4 && hist_may_move && !getenv("RTMC_LDS_HIST_LIMIT") &&
+        trace_waves_per_simd(align(lay.hist + 16)) > trace_waves_per_simd(with_hist))
+        lay.hist_in_hbm = 1u;
     lay.total = (uint32_t)(lay.hist_in_hbm ? align(lay.hist + 16) : with_hist);
     img.lds.assign(off, 0);
     if (n_el) memcpy(img.lds.data() + lay.elems, img.elems.data(), sizeof(DevElem<real>) * n_el);
@@ -2096,20 +2111,17 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
     const FrameSet fs = assign_frames(d);
     CellPlan plan = find_cells(d, fs, true);
     auto image32 = [&](int guide_bits, DeviceImage<float> &img) {
+        // (the histogram may move to HBM for the sake of occupancy where the scene then still runs a kernel with closed
+        // boxes: see rtmc_scene::cells_in_use and features)
+        const bool hist_may_move = plan.n_usable > 0 && !s->has_shapes && !s->has_aligned && !s->has_area && !s->has_coplanar &&
+                                   !s->seam_source;
         build_image<float>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx,
-                           s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, guide_bits, img);
+                           s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, guide_bits, hist_may_move, img);
     };
     // The guide tables of the inverse-CDF picks get as many buckets as the LDS can hold without costing the float32
     // kernel a wave per SIMD (workgroups of 512, 768 or 1024 threads, RTMC_TRACE_WAVES waves at most) or moving the
     // detector histogram to HBM: more buckets, fewer steps of bisection (C2 +2 % with 2^12 instead of 2^8).
-    auto waves_per_simd = [](size_t lds_bytes) {
-        int best = 0;
-        for (int block = TRACE_BLOCK; block <= TRACE_BLOCK_MAX; block += 256) {
-            const int resident = (int)(160 * 1024 / (lds_bytes + 1024));   // (a margin for the allocation granule)
-            best = std::max(best, std::min(RTMC_TRACE_WAVES, resident * block / 256));
-        }
-        return best;
-    };
+    auto waves_per_simd = [](size_t lds_bytes) { return trace_waves_per_simd(lds_bytes); };
     image32(GUIDE_BITS_MIN, s->img32);
     if (plan.n_regions > 0) {
         // the regions of a scene with many boxes (two records each): not at the price of a wave per SIMD, of the
@@ -2149,7 +2161,7 @@ static int scene_create_impl(const rtmc_scene_desc *d, rtmc_scene **out)
         }
         if (forced && atoi(forced) == GUIDE_BITS_MIN) s->guide_bits = GUIDE_BITS_MIN;
     }
-    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, GUIDE_BITS_MIN, s->img64);
+    build_image<double>(d, wl, cdfs, cdf_off, mat_cdfD, mat_cdfA, cdf_wid_off, mat_abs_slot, absA, absD, src_cdf, s->energy_fx, s->wid_cbin, (int)s->bins_used.size(), s->el_slot, s->n_dump, fs, plan, GUIDE_BITS_MIN, false, s->img64);
     s->has_back = s->img32.back_possible || s->img64.back_possible;
     s->has_frames = (s->img32.n_group[3] >> 16) != 0;
     s->has_runs = s->img32.has_runs;
@@ -2218,11 +2230,22 @@ static const void *trace_function(int features)
     if (features & (FEAT_AREA | FEAT_GUARD)) return (const void *)trace_kernel<real, FEAT_ALL>;
     if (features & FEAT_HBMHIST) {   // many detectors: the kernel with everything, or the kernels with cells that count in HBM
         if (sizeof(real) == 8 || !(features & FEAT_CELLS)) return (const void *)trace_kernel<real, FEAT_ALL>;
-        switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
-        case 0: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST>;
-        case FEAT_SPECTRA: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST | FEAT_SPECTRA>;
-        case FEAT_BACK: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST | FEAT_BACK>;
-        default: return (const void *)trace_kernel<real, FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST | FEAT_SPECTRA | FEAT_BACK>;
+        if constexpr (sizeof(real) == 4) {
+            constexpr int BASE = FEAT_CELLS | FEAT_RUNS | FEAT_HBMHIST;
+            if (features & FEAT_FRAMES) {   // ... in turned frames
+                switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+                case 0: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES>;
+                case FEAT_SPECTRA: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES | FEAT_SPECTRA>;
+                case FEAT_BACK: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES | FEAT_BACK>;
+                default: return (const void *)trace_kernel<real, BASE | FEAT_FRAMES | FEAT_SPECTRA | FEAT_BACK>;
+                }
+            }
+            switch (features & (FEAT_SPECTRA | FEAT_BACK)) {
+            case 0: return (const void *)trace_kernel<real, BASE>;
+            case FEAT_SPECTRA: return (const void *)trace_kernel<real, BASE | FEAT_SPECTRA>;
+            case FEAT_BACK: return (const void *)trace_kernel<real, BASE | FEAT_BACK>;
+            default: return (const void *)trace_kernel<real, BASE | FEAT_SPECTRA | FEAT_BACK>;
+            }
         }
     }
     if constexpr (sizeof(real) == 8) {

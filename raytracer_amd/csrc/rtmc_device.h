@@ -307,10 +307,11 @@ struct HotScene {
 // FEAT_CELLS (float32, rectangle-only scenes of the world frame; not part of FEAT_ALL): some rectangles close
 // boxes (DevCell); photons inside them find their next element without walking the list, the others wait for a
 // pass of the wave loop that walks it for all of them together.
-// FEAT_HBMHIST (only with everything else): detectors x wavelength bins exceed what the LDS
-// can hold beside the tables; every workgroup then counts hits with atomics in a histogram of
-// its own in HBM (one shared histogram is bounded by the rate of atomics on its few hot
-// words: 2e9 photons/s whatever the scene) and a second kernel adds the copies up.
+// FEAT_HBMHIST (with everything else, or with FEAT_CELLS): detectors x wavelength bins exceed what the
+// LDS can hold beside the tables, or would cost a kernel with cells a wave per SIMD there; every workgroup
+// then counts hits with atomics in a histogram of its own in HBM (one shared histogram is bounded by
+// the rate of atomics on its few hot words: 2e9 photons/s whatever the scene) and a second kernel adds
+// the copies up.
 enum : int { FEAT_ALIGNED = 1, FEAT_SHAPES = 2, FEAT_AREA = 4, FEAT_SPECTRA = 8, FEAT_BACK = 16, FEAT_FRAMES = 32, FEAT_GUARD = 64,
              FEAT_HBMHIST = 128, FEAT_RUNS = 256, FEAT_ALL = 511, FEAT_CELLS = 512 };
 

@@ -79,9 +79,10 @@ def test_regions_of_a_box_that_holds_several():
         assert s.cells()["regions"] == 11, s.cells()                 # (one region less than faces)
     finally:
         s.close()
-    # 16 stacked slabs: 96 faces, 15 gaps found twice.  41 slabs: the records of the regions would push the detector
-    # histogram out of the LDS, so the scene keeps its 42 boxes only
-    for n_slabs, want in ((16, (98, 81)), (41, (42, 0))):
+    # 8 stacked slabs: 48 faces, 7 gaps found twice.  16 slabs: with the detector histogram moved to HBM the scene tables
+    # leave room for six waves per SIMD, which the records of 81 regions would take back, so the scene keeps its 17
+    # boxes only; 41 slabs: the same for the histogram's place in the LDS
+    for n_slabs, want in ((8, (50, 41)), (16, (17, 0)), (41, (42, 0))):
         rt, s = _scene(configs.stacked_job(10, n_slabs=n_slabs))
         try:
             c = s.cells()
